@@ -1,0 +1,170 @@
+"""ctypes wrapper around oracle/_build/liboracle.so (the CPU oracle; test infrastructure only)."""
+import ctypes as C
+import os
+import subprocess
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE_DIR = os.path.join(ROOT, "oracle")
+ORACLE_SO = os.path.join(ORACLE_DIR, "_build", "liboracle.so")
+
+FLAG_ANYHIT_SHADOW = 1
+FLAG_NORMAL_ZYX = 2
+
+
+class V3(C.Structure):
+    _fields_ = [("x", C.c_float), ("y", C.c_float), ("z", C.c_float)]
+
+
+class SceneDesc(C.Structure):
+    _fields_ = [
+        ("width", C.c_int32), ("height", C.c_int32), ("bounces", C.c_int32), ("aa", C.c_int32),
+        ("dof_focus", C.c_float), ("dof_lens", C.c_float),
+        ("forward", V3), ("right", V3), ("up", V3), ("eye", V3),
+        ("expose", C.c_float),
+        ("fisheye", C.c_int32), ("panorama", C.c_int32), ("gi", C.c_int32),
+        ("num_spheres", C.c_int32), ("num_triangles", C.c_int32), ("num_prims", C.c_int32),
+        ("num_planes", C.c_int32), ("num_suns", C.c_int32), ("num_bulbs", C.c_int32),
+        ("spheres", C.c_void_p), ("triangles", C.c_void_p), ("prim_refs", C.c_void_p),
+        ("planes", C.c_void_p), ("suns", C.c_void_p), ("bulbs", C.c_void_p),
+    ]
+
+
+NODE = np.dtype([("xmin", "<f4"), ("xmax", "<f4"), ("ymin", "<f4"), ("ymax", "<f4"), ("zmin", "<f4"), ("zmax", "<f4"),
+                 ("left", "<u4"), ("right", "<u4"), ("prim_offset", "<u4"), ("count", "<u4")])
+HIT = np.dtype([("t", "<f4"), ("kind", "<u4"), ("id", "<u4"), ("n", "<f4", 3)])
+STAT_FIELDS = ["samples", "rays", "shadow_rays", "node_iters", "internal_visits", "sphere_tests", "tri_tests",
+               "mat_fetches", "max_stack", "prim_hits"]
+
+
+class Stats(C.Structure):
+    _fields_ = [(n, C.c_uint64) for n in STAT_FIELDS]
+
+    def as_dict(self):
+        return {n: int(getattr(self, n)) for n in STAT_FIELDS}
+
+
+def build_oracle():
+    """Compile the oracle if its .so is missing or stale (building the checker is not using it)."""
+    src = [os.path.join(ORACLE_DIR, f) for f in ("oracle.cpp", "omath.h", "Makefile")]
+    if os.path.exists(ORACLE_SO) and all(os.path.getmtime(ORACLE_SO) >= os.path.getmtime(s) for s in src):
+        return ORACLE_SO
+    subprocess.check_call(["make", "-C", ORACLE_DIR, "-s"])
+    return ORACLE_SO
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build_oracle()
+        L = C.CDLL(ORACLE_SO)
+        L.orc_scene_create.restype = C.c_void_p
+        L.orc_scene_create.argtypes = [C.POINTER(SceneDesc)]
+        L.orc_scene_destroy.argtypes = [C.c_void_p]
+        L.orc_build_lbvh.argtypes = [C.c_void_p, C.c_int]
+        L.orc_num_nodes.argtypes = [C.c_void_p]
+        for fn in ("orc_get_nodes", "orc_get_codes", "orc_get_refs"):
+            getattr(L, fn).argtypes = [C.c_void_p, C.c_void_p]
+        L.orc_get_bounds.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.orc_render.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                 C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(Stats), C.c_uint32, C.c_int]
+        L.orc_render_subsample.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(Stats), C.c_uint32,
+                                           C.c_int, C.POINTER(C.c_float)]
+        L.orc_xorwow_seq.argtypes = [C.c_uint64, C.c_uint64, C.c_uint64, C.c_int, C.c_void_p]
+        L.orc_xorwow_state.argtypes = [C.c_uint64, C.c_uint64, C.c_void_p]
+        L.orc_xorwow_floats.argtypes = [C.c_uint64, C.c_uint64, C.c_int, C.c_int, C.c_void_p]
+        L.orc_jump_matrix.argtypes = [C.c_int, C.c_void_p]
+        L.orc_math_probe.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+        L.orc_morton.restype = C.c_uint32
+        L.orc_morton.argtypes = [C.c_float, C.c_float, C.c_float, C.c_void_p, C.c_void_p]
+        L.orc_sizeof.argtypes = [C.c_int]
+        _lib = L
+    return _lib
+
+
+def _vec(v):
+    return V3(float(v[0]), float(v[1]), float(v[2]))
+
+
+def make_desc(sc, arrays, desc_cls=SceneDesc):
+    """Fill a scene descriptor from a tests.pyscene.PyScene (or anything with the same attributes)."""
+    d = desc_cls()
+    d.width, d.height, d.bounces, d.aa = sc.width, sc.height, sc.bounces, sc.aa
+    d.dof_focus, d.dof_lens = float(sc.dof_focus), float(sc.dof_lens)
+    d.forward, d.right, d.up, d.eye = _vec(sc.forward), _vec(sc.right), _vec(sc.up), _vec(sc.eye)
+    d.expose = float(sc.expose)
+    d.fisheye, d.panorama, d.gi = int(sc.fisheye), int(sc.panorama), sc.gi
+    d.num_spheres, d.num_triangles, d.num_prims = len(arrays["spheres"]), len(arrays["triangles"]), len(arrays["refs"])
+    d.num_planes, d.num_suns, d.num_bulbs = len(arrays["planes"]), len(arrays["suns"]), len(arrays["bulbs"])
+    for name, key in (("spheres", "spheres"), ("triangles", "triangles"), ("prim_refs", "refs"),
+                      ("planes", "planes"), ("suns", "suns"), ("bulbs", "bulbs")):
+        a = arrays[key]
+        setattr(d, name, a.ctypes.data if len(a) else None)
+    return d
+
+
+class OracleScene:
+    """Owns an oracle scene handle.  bounds_mode 0 = true scene bounds, 1 = as shipped (all Morton codes 0)."""
+
+    def __init__(self, pyscene, bounds_mode=0, build=True):
+        self.sc = pyscene
+        self.arrays = pyscene.arrays()
+        self.desc = make_desc(pyscene, self.arrays)
+        self.h = lib().orc_scene_create(C.byref(self.desc))
+        self.n = len(self.arrays["refs"])
+        if build:
+            assert lib().orc_build_lbvh(self.h, bounds_mode) == 0
+
+    def close(self):
+        if self.h:
+            lib().orc_scene_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def nodes(self):
+        n = lib().orc_num_nodes(self.h)
+        out = np.zeros(n, dtype=NODE)
+        lib().orc_get_nodes(self.h, out.ctypes.data)
+        return out
+
+    def codes(self):
+        out = np.zeros(self.n, dtype=np.uint32)
+        lib().orc_get_codes(self.h, out.ctypes.data)
+        return out
+
+    def refs(self):
+        out = np.zeros(self.n, dtype=[("type", "<u4"), ("id", "<u4")])
+        lib().orc_get_refs(self.h, out.ctypes.data)
+        return out
+
+    def bounds(self):
+        mn = np.zeros(3, np.float32)
+        mx = np.zeros(3, np.float32)
+        lib().orc_get_bounds(self.h, mn.ctypes.data, mx.ctypes.data)
+        return mn, mx
+
+    def render(self, width, height, spp, tile=None, flags=0, nthreads=1, want_aov=False):
+        x0, y0, tw, th = tile if tile else (0, 0, width, height)
+        f = np.zeros((th, tw, 4), np.float32)
+        u = np.zeros((th, tw, 4), np.uint8)
+        aov = np.zeros((th, tw), HIT) if want_aov else None
+        st = Stats()
+        rc = lib().orc_render(self.h, width, height, spp, x0, y0, tw, th, f.ctypes.data, u.ctypes.data,
+                              aov.ctypes.data if want_aov else None, C.byref(st), flags, nthreads)
+        assert rc == 0
+        return dict(f32=f, u8=u, aov=aov, stats=st.as_dict())
+
+    def render_subsample(self, width, height, spp, step, flags=0, nthreads=1):
+        st = Stats()
+        cs = C.c_float(0)
+        rc = lib().orc_render_subsample(self.h, width, height, spp, step, C.byref(st), flags, nthreads, C.byref(cs))
+        assert rc == 0
+        return st.as_dict(), float(cs.value)
