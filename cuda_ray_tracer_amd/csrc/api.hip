@@ -1,0 +1,201 @@
+// C ABI glue for the device side of libmirt.so (include/mirt.h): scene upload, build, render, stats.
+#include "scene_dev.h"
+#include "host_scene.h"
+
+#include <cstring>
+#include <vector>
+
+using namespace mirt;
+
+namespace {
+
+template <typename T>
+int upload(T** dst, const std::vector<T>& src)
+{
+  *dst = nullptr;
+  if (src.empty()) return MIRT_OK;
+  MIRT_HIP(hipMalloc(dst, sizeof(T) * src.size()));
+  MIRT_HIP(hipMemcpy(*dst, src.data(), sizeof(T) * src.size(), hipMemcpyHostToDevice));
+  return MIRT_OK;
+}
+
+bool nonzero(const MirtRGB& c) { return !(fabsf(c.r) < 1e-6f && fabsf(c.g) < 1e-6f && fabsf(c.b) < 1e-6f); }
+
+void pack_mat(const MirtMaterials& m, float4* out)
+{
+  out[0] = make_float4(m.color.r, m.color.g, m.color.b, m.shininess.r);
+  out[1] = make_float4(m.shininess.g, m.shininess.b, m.trans.r, m.trans.g);
+  out[2] = make_float4(m.trans.b, m.ior, m.roughness, 0.0f);
+}
+
+} // namespace
+
+extern "C" {
+
+int mirt_scene_create(const MirtSceneDesc* d, int device, MirtScene** out)
+{
+  if (!d || !out) { set_error("mirt_scene_create: null argument"); return MIRT_ERR_ARG; }
+  if (d->num_prims != d->num_spheres + d->num_triangles) { set_error("mirt_scene_create: num_prims != num_spheres + num_triangles"); return MIRT_ERR_ARG; }
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+    set_error("mirt_scene_create: no HIP device available (libmirt has no CPU path)");
+    return MIRT_ERR_NO_DEVICE;
+  }
+  if (device < 0 || device >= ndev) { set_error("mirt_scene_create: bad device index"); return MIRT_ERR_ARG; }
+  MIRT_HIP(hipSetDevice(device));
+
+  MirtScene* sc = new MirtScene();
+  sc->device = device;
+  sc->d = *d;
+  sc->N = d->num_prims; sc->Ns = d->num_spheres; sc->Nt = d->num_triangles;
+  const int N = sc->N;
+
+  // de-interleave the AoS inputs into the device layout (config_utils.cu:72-199 does the same job for the reference)
+  std::vector<float4> spheres((size_t)sc->Ns), tris(3 * (size_t)sc->Nt), verts(3 * (size_t)sc->Nt), mats(3 * (size_t)N);
+  for (int i = 0; i < sc->Ns; ++i) {
+    const MirtSphere& s = d->spheres[i];
+    spheres[i] = make_float4(s.c.x, s.c.y, s.c.z, s.r);
+    pack_mat(s.mat, &mats[3 * (size_t)i]);
+    if (nonzero(s.mat.trans)) sc->any_trans = true;
+    if (s.mat.roughness > 0.0f) sc->any_rough = true;
+  }
+  for (int i = 0; i < sc->Nt; ++i) {
+    const MirtTriangle& t = d->triangles[i];
+    tris[3 * (size_t)i + 0] = make_float4(t.p0.x, t.p0.y, t.p0.z, t.nor.x);
+    tris[3 * (size_t)i + 1] = make_float4(t.nor.y, t.nor.z, t.e1.x, t.e1.y);
+    tris[3 * (size_t)i + 2] = make_float4(t.e1.z, t.e2.x, t.e2.y, t.e2.z);
+    verts[3 * (size_t)i + 0] = make_float4(t.p0.x, t.p0.y, t.p0.z, 0.0f);
+    verts[3 * (size_t)i + 1] = make_float4(t.p1.x, t.p1.y, t.p1.z, 0.0f);
+    verts[3 * (size_t)i + 2] = make_float4(t.p2.x, t.p2.y, t.p2.z, 0.0f);
+    pack_mat(t.mat, &mats[3 * ((size_t)sc->Ns + i)]);
+    if (nonzero(t.mat.trans)) sc->any_trans = true;
+    if (t.mat.roughness > 0.0f) sc->any_rough = true;
+  }
+  std::vector<MirtPrimRef> refs(d->prim_refs, d->prim_refs + N);
+  for (int i = 0; i < N; ++i) {
+    const MirtPrimRef& r = refs[i];
+    if (r.type > 1 || (r.type == 0 && (int)r.id >= sc->Ns) || (r.type == 1 && (int)r.id >= sc->Nt)) {
+      delete sc; set_error("mirt_scene_create: primitive reference out of range"); return MIRT_ERR_ARG;
+    }
+  }
+  std::vector<PlaneDev> planes((size_t)d->num_planes);
+  for (int i = 0; i < d->num_planes; ++i) {
+    const MirtPlane& p = d->planes[i];
+    PlaneDev& q = planes[i];
+    q.nx = p.nor.x; q.ny = p.nor.y; q.nz = p.nor.z; q.px = p.point.x; q.py = p.point.y; q.pz = p.point.z;
+    const float m[11] = {p.mat.color.r, p.mat.color.g, p.mat.color.b, p.mat.shininess.r, p.mat.shininess.g, p.mat.shininess.b,
+                         p.mat.trans.r, p.mat.trans.g, p.mat.trans.b, p.mat.ior, p.mat.roughness};
+    memcpy(q.mat, m, sizeof(m)); q.pad = 0.0f;
+    if (nonzero(p.mat.trans)) sc->any_trans = true;
+    if (p.mat.roughness > 0.0f) sc->any_rough = true;
+  }
+  std::vector<LightDev> suns((size_t)d->num_suns), bulbs((size_t)d->num_bulbs);
+  for (int i = 0; i < d->num_suns; ++i) suns[i] = {d->suns[i].dir.x, d->suns[i].dir.y, d->suns[i].dir.z, d->suns[i].color.r, d->suns[i].color.g, d->suns[i].color.b};
+  for (int i = 0; i < d->num_bulbs; ++i) bulbs[i] = {d->bulbs[i].point.x, d->bulbs[i].point.y, d->bulbs[i].point.z, d->bulbs[i].color.r, d->bulbs[i].color.g, d->bulbs[i].color.b};
+  sc->d.spheres = nullptr; sc->d.triangles = nullptr; sc->d.prim_refs = nullptr; sc->d.planes = nullptr; sc->d.suns = nullptr; sc->d.bulbs = nullptr;
+
+  int rc = MIRT_OK;
+  auto chk = [&](int r) { if (rc == MIRT_OK) rc = r; };
+  chk(upload(&sc->spheres, spheres)); chk(upload(&sc->tris, tris)); chk(upload(&sc->tri_verts, verts)); chk(upload(&sc->mats, mats));
+  chk(upload(&sc->refs_in, refs)); chk(upload(&sc->planes, planes)); chk(upload(&sc->suns, suns)); chk(upload(&sc->bulbs, bulbs));
+  auto alloc = [&](void** p, size_t bytes) { if (rc == MIRT_OK && bytes) { hipError_t e = hipMalloc(p, bytes); if (e != hipSuccess) rc = hip_fail(e, "hipMalloc", __FILE__, __LINE__); } };
+  if (N > 0) {
+    alloc((void**)&sc->codes, 4 * (size_t)N); alloc((void**)&sc->order, 4 * (size_t)N);
+    alloc((void**)&sc->parent, 4 * (2 * (size_t)N - 1)); alloc((void**)&sc->boxes, 24 * (2 * (size_t)N - 1));
+    if (N > 1) { alloc((void**)&sc->child_l, 4 * (size_t)(N - 1)); alloc((void**)&sc->child_r, 4 * (size_t)(N - 1)); alloc((void**)&sc->nodes, 64 * (size_t)(N - 1)); }
+  }
+  alloc((void**)&sc->bounds_keys, 6 * 4);
+  alloc((void**)&sc->counters, 8 * sizeof(unsigned long long));
+  if (rc == MIRT_OK) {
+    hipError_t e = hipEventCreate(&sc->ev0);
+    if (e == hipSuccess) e = hipEventCreate(&sc->ev1);
+    if (e == hipSuccess) e = hipEventCreate(&sc->ev2);
+    if (e == hipSuccess) e = hipEventCreate(&sc->ev3);
+    if (e != hipSuccess) rc = hip_fail(e, "hipEventCreate", __FILE__, __LINE__);
+  }
+  if (rc != MIRT_OK) { mirt_scene_destroy(sc); return rc; }
+  *out = sc;
+  return MIRT_OK;
+}
+
+void mirt_scene_destroy(MirtScene* sc)
+{
+  if (!sc) return;
+  hipSetDevice(sc->device);
+  hipDeviceSynchronize();
+  hipFree(sc->spheres); hipFree(sc->tris); hipFree(sc->tri_verts); hipFree(sc->mats); hipFree(sc->refs_in);
+  hipFree(sc->planes); hipFree(sc->suns); hipFree(sc->bulbs);
+  hipFree(sc->codes); hipFree(sc->order); hipFree(sc->child_l); hipFree(sc->child_r); hipFree(sc->parent); hipFree(sc->boxes); hipFree(sc->nodes);
+  hipFree(sc->bounds_keys); hipFree(sc->samples); hipFree(sc->stack_spill); hipFree(sc->pending); hipFree(sc->counters);
+  rng_cache_free(&sc->rng);
+  if (sc->ev0) hipEventDestroy(sc->ev0);
+  if (sc->ev1) hipEventDestroy(sc->ev1);
+  if (sc->ev2) hipEventDestroy(sc->ev2);
+  if (sc->ev3) hipEventDestroy(sc->ev3);
+  delete sc;
+}
+
+int mirt_build_lbvh(MirtScene* sc, void* stream, float* build_ms)
+{
+  if (!sc) { set_error("mirt_build_lbvh: null scene"); return MIRT_ERR_ARG; }
+  MIRT_HIP(hipSetDevice(sc->device));
+  int rc = build_lbvh(sc, (hipStream_t)stream);
+  if (rc == MIRT_OK && build_ms) *build_ms = sc->build_ms;
+  return rc;
+}
+
+int64_t mirt_render_num_pixels(const MirtRenderParams* p) { return p ? render_num_pixels(p) : -1; }
+
+int mirt_render(MirtScene* sc, const MirtRenderParams* p, void* d_rgba8, void* d_rgba_f32, void* stream)
+{
+  if (!sc || !p) { set_error("mirt_render: null argument"); return MIRT_ERR_ARG; }
+  MIRT_HIP(hipSetDevice(sc->device));
+  return render(sc, p, d_rgba8, d_rgba_f32, (hipStream_t)stream);
+}
+
+int mirt_scatter_part(const MirtRenderParams* p, const void* d_part_rgba8, void* d_frame_rgba8, void* stream)
+{
+  if (!p) { set_error("mirt_scatter_part: null argument"); return MIRT_ERR_ARG; }
+  return scatter_part(p, d_part_rgba8, d_frame_rgba8, (hipStream_t)stream);
+}
+
+int mirt_get_stats(MirtScene* sc, MirtStats* out)
+{
+  if (!sc || !out) { set_error("mirt_get_stats: null argument"); return MIRT_ERR_ARG; }
+  memset(out, 0, sizeof(*out));
+  MIRT_HIP(hipSetDevice(sc->device));
+  out->build_ms = sc->build_ms;
+  out->num_nodes = sc->N > 0 ? 2 * sc->N - 1 : 0;
+  if (!sc->have_render) return MIRT_OK;
+  MIRT_HIP(hipEventSynchronize(sc->ev3));
+  MIRT_HIP(hipEventElapsedTime(&out->trace_kernel_ms, sc->ev1, sc->ev2));
+  MIRT_HIP(hipEventElapsedTime(&out->render_ms, sc->ev0, sc->ev3));
+  if (sc->last_counted) {
+    unsigned long long c[8];
+    MIRT_HIP(hipMemcpy(c, sc->counters, sizeof(c), hipMemcpyDeviceToHost));
+    out->samples = c[0]; out->rays = c[1]; out->shadow_rays = c[2]; out->internal_visits = c[3];
+    out->sphere_tests = c[4]; out->tri_tests = c[5]; out->mat_fetches = c[6]; out->max_stack = c[7];
+  }
+  return MIRT_OK;
+}
+
+int mirt_get_tree(MirtScene* sc, MirtTreeNode* nodes, uint32_t* codes, MirtPrimRef* refs, float* bounds)
+{
+  if (!sc) { set_error("mirt_get_tree: null scene"); return MIRT_ERR_ARG; }
+  MIRT_HIP(hipSetDevice(sc->device));
+  return get_tree(sc, nodes, codes, refs, bounds);
+}
+
+int mirt_probe_math(int device, int which, int n, const float* host_in, float* host_out)
+{
+  if (n <= 0 || !host_in || !host_out) { set_error("mirt_probe_math: bad argument"); return MIRT_ERR_ARG; }
+  return probe_math(device, which, n, host_in, host_out);
+}
+
+int mirt_probe_xorwow(int device, int spp, int num_streams, int draws, uint32_t* host_out)
+{
+  if (num_streams <= 0 || draws <= 0 || !host_out) { set_error("mirt_probe_xorwow: bad argument"); return MIRT_ERR_ARG; }
+  return probe_xorwow(device, spp, num_streams, draws, host_out);
+}
+
+} // extern "C"

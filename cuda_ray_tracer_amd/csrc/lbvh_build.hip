@@ -1,0 +1,442 @@
+// LBVH build on the device: replaces build_lbvh_karas (lbvh_builder.cu:401-521) and
+// build_morton_codes_and_sort_primitives (lbvh_utils.cu:77-129).
+//
+//   prim_bounds_kernel   scene bounds = union of primitive boxes (what parse.cpp:147-155,193-200 computes on the
+//                        host and then drops -- reference bug #1; here the bounds are real)
+//   morton_kernel        30-bit codes (lbvh_utils.cu:10-75)
+//   radix_pass_kernel    stable LSD radix sort, 4 passes x 8 bits, wave64 ballot ranking (replaces thrust::sort_by_key)
+//   karras_kernel        Karras 2012 hierarchy with the reference's index tie-break (lbvh_builder.cu:76-322)
+//   refit_pack_kernel    bottom-up boxes (lbvh_builder.cu:324-387, with the missing release/acquire added) and
+//                        64-byte two-child node records for the traversal kernel
+#include "scene_dev.h"
+#include "host_scene.h"
+
+#include <cstdio>
+#include <cstring>
+
+namespace mirt {
+
+int hip_fail(hipError_t e, const char* what, const char* file, int line)
+{
+  char buf[512];
+  snprintf(buf, sizeof(buf), "HIP error in %s at line %d: %s (%s)", file, line, hipGetErrorString(e), what);
+  set_error(buf);
+  return MIRT_ERR_HIP;
+}
+
+namespace {
+
+constexpr int BLOCK = 256;
+
+struct Box { float xmin, xmax, ymin, ymax, zmin, zmax; };
+
+// get_primitive_aabb_device, lbvh_builder.cu:33-57 with AABB ctors interval.cuh:55-81
+MIRT_DEV Box prim_box(uint32_t type, uint32_t id, const float4* __restrict__ spheres, const float4* __restrict__ tri_verts)
+{
+  Box b;
+  if (type == 0) {
+    const float4 s = spheres[id];
+    const float ax = s.x - s.w, bx = s.x + s.w;
+    const float ay = s.y - s.w, by = s.y + s.w;
+    const float az = s.z - s.w, bz = s.z + s.w;
+    if (ax <= bx) { b.xmin = ax; b.xmax = bx; } else { b.xmin = bx; b.xmax = ax; }
+    if (ay <= by) { b.ymin = ay; b.ymax = by; } else { b.ymin = by; b.ymax = ay; }
+    if (az <= bz) { b.zmin = az; b.zmax = bz; } else { b.zmin = bz; b.zmax = az; }
+  } else {
+    const float4 p0 = tri_verts[3 * (size_t)id + 0], p1 = tri_verts[3 * (size_t)id + 1], p2 = tri_verts[3 * (size_t)id + 2];
+    b.xmin = fminf(fminf(p0.x, p1.x), p2.x); b.xmax = fmaxf(fmaxf(p0.x, p1.x), p2.x);
+    b.ymin = fminf(fminf(p0.y, p1.y), p2.y); b.ymax = fmaxf(fmaxf(p0.y, p1.y), p2.y);
+    b.zmin = fminf(fminf(p0.z, p1.z), p2.z); b.zmax = fmaxf(fmaxf(p0.z, p1.z), p2.z);
+    if (b.xmax - b.xmin < 0.01f) { b.xmin = b.xmin - 0.01f; b.xmax = b.xmax + 0.01f; }
+    if (b.ymax - b.ymin < 0.01f) { b.ymin = b.ymin - 0.01f; b.ymax = b.ymax + 0.01f; }
+    if (b.zmax - b.zmin < 0.01f) { b.zmin = b.zmin - 0.01f; b.zmax = b.zmax + 0.01f; }
+  }
+  return b;
+}
+
+// order-preserving float <-> uint map so that atomicMin/atomicMax on uints realise float min/max
+MIRT_DEV uint32_t f2key(float f) { uint32_t u = __float_as_uint(f); return (u & 0x80000000u) ? ~u : (u | 0x80000000u); }
+MIRT_DEV float key2f(uint32_t k) { return __uint_as_float((k & 0x80000000u) ? (k & 0x7fffffffu) : ~k); }
+
+__global__ void __launch_bounds__(BLOCK) prim_bounds_kernel(const MirtPrimRef* __restrict__ refs, const float4* __restrict__ spheres,
+                                                            const float4* __restrict__ tri_verts, int n, uint32_t* __restrict__ keys)
+{
+  float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
+  for (int i = blockIdx.x * BLOCK + threadIdx.x; i < n; i += gridDim.x * BLOCK) {
+    const MirtPrimRef r = refs[i];
+    const Box b = prim_box(r.type, r.id, spheres, tri_verts);
+    mn[0] = fminf(mn[0], b.xmin); mx[0] = fmaxf(mx[0], b.xmax);
+    mn[1] = fminf(mn[1], b.ymin); mx[1] = fmaxf(mx[1], b.ymax);
+    mn[2] = fminf(mn[2], b.zmin); mx[2] = fmaxf(mx[2], b.zmax);
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1)
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      mn[k] = fminf(mn[k], __shfl_xor(mn[k], off));
+      mx[k] = fmaxf(mx[k], __shfl_xor(mx[k], off));
+    }
+  if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      atomicMin(&keys[k], f2key(mn[k]));
+      atomicMax(&keys[3 + k], f2key(mx[k]));
+    }
+  }
+}
+
+// lbvh_utils.cu:10-30
+MIRT_DEV uint32_t expand_bits(uint32_t v)
+{
+  v = (v * 0x00010001u) & 0xFF0000FFu;
+  v = (v * 0x00000101u) & 0x0F00F00Fu;
+  v = (v * 0x00000011u) & 0xC30C30C3u;
+  v = (v * 0x00000005u) & 0x49249249u;
+  return v;
+}
+MIRT_DEV uint32_t quantize_coordinate(float coord, float smin, float range)
+{
+  if (range <= 1e-6f) return 0;
+  float normalized = (coord - smin) / range;
+  normalized = fmaxf(0.0f, fminf(1.0f, normalized));
+  return (uint32_t)(normalized * 1023);
+}
+
+// generate_morton_codes_kernel, lbvh_utils.cu:32-75
+__global__ void __launch_bounds__(BLOCK) morton_kernel(const MirtPrimRef* __restrict__ refs, const float4* __restrict__ spheres,
+                                                       const float4* __restrict__ tri_verts, int n, const uint32_t* __restrict__ bkeys,
+                                                       uint32_t* __restrict__ keys, uint32_t* __restrict__ vals)
+{
+  const int i = blockIdx.x * BLOCK + threadIdx.x;
+  if (i >= n) return;
+  const float mnx = key2f(bkeys[0]), mny = key2f(bkeys[1]), mnz = key2f(bkeys[2]);
+  const float mxx = key2f(bkeys[3]), mxy = key2f(bkeys[4]), mxz = key2f(bkeys[5]);
+  const MirtPrimRef r = refs[i];
+  float cx, cy, cz;
+  if (r.type == 0) {
+    const float4 s = spheres[r.id];
+    cx = s.x; cy = s.y; cz = s.z;
+  } else {
+    const float4 p0 = tri_verts[3 * (size_t)r.id + 0], p1 = tri_verts[3 * (size_t)r.id + 1], p2 = tri_verts[3 * (size_t)r.id + 2];
+    cx = ((p0.x + p1.x) + p2.x) / 3.0f;
+    cy = ((p0.y + p1.y) + p2.y) / 3.0f;
+    cz = ((p0.z + p1.z) + p2.z) / 3.0f;
+  }
+  const uint32_t qx = quantize_coordinate(cx, mnx, mxx - mnx);
+  const uint32_t qy = quantize_coordinate(cy, mny, mxy - mny);
+  const uint32_t qz = quantize_coordinate(cz, mnz, mxz - mnz);
+  keys[i] = expand_bits(qx) | (expand_bits(qy) << 1) | (expand_bits(qz) << 2);
+  vals[i] = (uint32_t)i;
+}
+
+// ---- stable LSD radix sort -------------------------------------------------------------------------
+constexpr int SORT_ITEMS = 8;
+constexpr int SORT_TILE = BLOCK * SORT_ITEMS;   // 2048 keys per workgroup; each wave owns 512 consecutive keys
+
+template <bool SCATTER>
+__global__ void __launch_bounds__(BLOCK) radix_pass_kernel(const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in,
+                                                           uint32_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out,
+                                                           uint32_t* __restrict__ hist, const uint32_t* __restrict__ offsets,
+                                                           int n, int shift, int nblocks)
+{
+  __shared__ uint32_t wcnt[4][256];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  for (int i = tid; i < 4 * 256; i += BLOCK) (&wcnt[0][0])[i] = 0;
+  __syncthreads();
+
+  const int base = blockIdx.x * SORT_TILE + wave * (SORT_ITEMS * 64);
+  uint32_t key[SORT_ITEMS], rank[SORT_ITEMS];
+  const unsigned long long lt = (1ull << lane) - 1ull;
+#pragma unroll
+  for (int it = 0; it < SORT_ITEMS; ++it) {
+    const int idx = base + it * 64 + lane;
+    const bool valid = idx < n;
+    key[it] = valid ? keys_in[idx] : 0xffffffffu;
+    const uint32_t digit = (key[it] >> shift) & 255u;
+    unsigned long long mask = __ballot(valid);
+#pragma unroll
+    for (int b = 0; b < 8; ++b) {
+      const bool bit = (digit >> b) & 1u;
+      const unsigned long long bal = __ballot(valid && bit);
+      mask &= bit ? bal : ~bal;
+    }
+    const uint32_t r = (uint32_t)__popcll(mask & lt);
+    const uint32_t c = (uint32_t)__popcll(mask);
+    uint32_t prev = 0;
+    if (valid) prev = wcnt[wave][digit];
+    rank[it] = prev + r;
+    __builtin_amdgcn_wave_barrier();
+    if (valid && r == 0) wcnt[wave][digit] = prev + c;
+    __builtin_amdgcn_wave_barrier();
+  }
+  __syncthreads();
+  const uint32_t c0 = wcnt[0][tid], c1 = wcnt[1][tid], c2 = wcnt[2][tid], c3 = wcnt[3][tid];
+  if (!SCATTER) {
+    hist[(size_t)tid * nblocks + blockIdx.x] = c0 + c1 + c2 + c3;
+    return;
+  }
+  const uint32_t off = offsets[(size_t)tid * nblocks + blockIdx.x];
+  __syncthreads();
+  wcnt[0][tid] = off; wcnt[1][tid] = off + c0; wcnt[2][tid] = off + c0 + c1; wcnt[3][tid] = off + c0 + c1 + c2;
+  __syncthreads();
+#pragma unroll
+  for (int it = 0; it < SORT_ITEMS; ++it) {
+    const int idx = base + it * 64 + lane;
+    if (idx < n) {
+      const uint32_t digit = (key[it] >> shift) & 255u;
+      const uint32_t pos = wcnt[wave][digit] + rank[it];
+      keys_out[pos] = key[it];
+      vals_out[pos] = vals_in[idx];
+    }
+  }
+}
+
+// exclusive scan of hist[total] in place -> offsets; one workgroup of 1024 threads
+__global__ void __launch_bounds__(1024) scan_kernel(uint32_t* __restrict__ data, int total)
+{
+  __shared__ uint32_t sums[1024];
+  const int tid = threadIdx.x;
+  const int chunk = (total + 1023) / 1024;
+  const int lo = tid * chunk, hi = min(lo + chunk, total);
+  uint32_t s = 0;
+  for (int i = lo; i < hi; ++i) s += data[i];
+  sums[tid] = s;
+  __syncthreads();
+  for (int off = 1; off < 1024; off <<= 1) {
+    uint32_t v = (tid >= off) ? sums[tid - off] : 0;
+    __syncthreads();
+    sums[tid] += v;
+    __syncthreads();
+  }
+  uint32_t run = sums[tid] - s;   // exclusive
+  for (int i = lo; i < hi; ++i) { uint32_t v = data[i]; data[i] = run; run += v; }
+}
+
+// ---- Karras hierarchy ------------------------------------------------------------------------------
+MIRT_DEV int clz32(uint32_t x) { return x ? __clz((int)x) : 32; }
+// adapted_delta, lbvh_builder.cu:76-101
+MIRT_DEV int delta(int a, int b, int n, const uint32_t* __restrict__ codes)
+{
+  if (a < 0 || a >= n || b < 0 || b >= n) return -1;
+  const uint32_t ka = codes[a], kb = codes[b];
+  if (ka == kb) return 32 + clz32((uint32_t)a ^ (uint32_t)b);
+  return clz32(ka ^ kb);
+}
+
+// generate_internal_nodes_karas_kernel, lbvh_builder.cu:224-322 (+ determine_range_adapted :103-182,
+// find_split_adapted :186-221).  Children use the reference numbering: internal i in [0,N-2], leaf j -> N-1+j.
+__global__ void __launch_bounds__(BLOCK) karras_kernel(const uint32_t* __restrict__ codes, int n, uint32_t* __restrict__ child_l,
+                                                       uint32_t* __restrict__ child_r, int* __restrict__ parent)
+{
+  const int i = blockIdx.x * BLOCK + threadIdx.x;
+  if (i >= n - 1) return;
+  // range
+  const int dl = delta(i, i - 1, n, codes), dr = delta(i, i + 1, n, codes);
+  int d, dmin;
+  if (dr > dl) { d = 1; dmin = dl; } else { d = -1; dmin = dr; }
+  uint32_t lmax = 1;
+  int nb = (int)((uint32_t)i + lmax * (uint32_t)d);
+  int cur = delta(i, nb, n, codes);
+  while (cur > dmin) {
+    lmax <<= 1;
+    nb = (int)((uint32_t)i + lmax * (uint32_t)d);
+    if (nb < 0 || nb >= n) break;
+    cur = delta(i, nb, n, codes);
+  }
+  uint32_t l = 0;
+  for (uint32_t t = lmax >> 1; t > 0; t >>= 1) {
+    const int nbb = (int)((uint32_t)i + (l + t) * (uint32_t)d);
+    if (nbb >= 0 && nbb < n) {
+      if (delta(i, nbb, n, codes) > dmin) l += t;
+    }
+  }
+  const int j = (int)((uint32_t)i + l * (uint32_t)d);
+  const int first = (i < j) ? i : j, last = (i < j) ? j : i;
+  // split
+  int split = first;
+  if (first != last) {
+    const int common = delta(first, last, n, codes);
+    int step = last - first;
+    do {
+      step = (step + 1) >> 1;
+      const int cand = split + step;
+      if (cand < last) {
+        if (delta(first, cand, n, codes) > common) split = cand;
+      }
+    } while (step > 1);
+  }
+  if (split < first || split >= last) {   // cannot happen for a valid range; mirror the reference's marker
+    child_l[i] = 0xffffffffu; child_r[i] = 0xffffffffu;
+    return;
+  }
+  const uint32_t leaf_base = (uint32_t)(n - 1);
+  const int d_split = delta(split, split + 1, n, codes);
+  uint32_t lc, rc;
+  if (split == first) lc = leaf_base + (uint32_t)split;
+  else lc = (delta(first, split, n, codes) > d_split) ? (uint32_t)split : leaf_base + (uint32_t)first;
+  if (split + 1 == last) rc = leaf_base + (uint32_t)last;
+  else rc = (delta(split + 1, last, n, codes) > d_split) ? (uint32_t)(split + 1) : leaf_base + (uint32_t)last;
+  child_l[i] = lc; child_r[i] = rc;
+  parent[lc] = i; parent[rc] = i;
+  if (i == 0) parent[0] = -1;
+}
+
+MIRT_DEV uint32_t make_ref(uint32_t node, uint32_t leaf_base, const uint32_t* __restrict__ order, const MirtPrimRef* __restrict__ refs)
+{
+  if (node < leaf_base) return node;
+  const MirtPrimRef r = refs[order[node - leaf_base]];
+  return REF_LEAF | (r.type ? REF_TRI : 0u) | (r.id & REF_IDMASK);
+}
+
+// set_aabb_kernel_adapted, lbvh_builder.cu:324-387.  One thread per leaf; the second thread to arrive at a parent
+// merges the children.  The box stores are published by the acq_rel fetch_add on the arrival counter (the reference
+// has no fence there).  The merging thread also writes the parent's packed traversal record.
+__global__ void __launch_bounds__(BLOCK) refit_pack_kernel(int n, const uint32_t* __restrict__ order, const MirtPrimRef* __restrict__ refs,
+                                                           const float4* __restrict__ spheres, const float4* __restrict__ tri_verts,
+                                                           const uint32_t* __restrict__ child_l, const uint32_t* __restrict__ child_r,
+                                                           const int* __restrict__ parent, uint32_t* __restrict__ arrived,
+                                                           float* boxes, float4* __restrict__ nodes)
+{
+  const int j = blockIdx.x * BLOCK + threadIdx.x;
+  if (j >= n) return;
+  const uint32_t leaf_base = (uint32_t)(n - 1);
+  uint32_t cur = leaf_base + (uint32_t)j;
+  const MirtPrimRef r = refs[order[j]];
+  const Box b = prim_box(r.type, r.id, spheres, tri_verts);
+  float* bp = boxes + 6 * (size_t)cur;
+  bp[0] = b.xmin; bp[1] = b.xmax; bp[2] = b.ymin; bp[3] = b.ymax; bp[4] = b.zmin; bp[5] = b.zmax;
+  int p = parent[cur];
+  while (p != -1 && p < n - 1) {
+    const uint32_t prev = __hip_atomic_fetch_add(&arrived[p], 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+    if (prev == 0) break;
+    const uint32_t lc = child_l[p], rc = child_r[p];
+    const float* a = boxes + 6 * (size_t)lc;
+    const float* c = boxes + 6 * (size_t)rc;
+    const float a0 = __hip_atomic_load(a + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), a1 = __hip_atomic_load(a + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const float a2 = __hip_atomic_load(a + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), a3 = __hip_atomic_load(a + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const float a4 = __hip_atomic_load(a + 4, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), a5 = __hip_atomic_load(a + 5, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const float c0 = __hip_atomic_load(c + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), c1 = __hip_atomic_load(c + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const float c2 = __hip_atomic_load(c + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), c3 = __hip_atomic_load(c + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const float c4 = __hip_atomic_load(c + 4, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), c5 = __hip_atomic_load(c + 5, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // traversal record: child boxes as (min xyz, max xyz) pairs + child references
+    float4* rec = nodes + 4 * (size_t)p;
+    rec[0] = make_float4(a0, a2, a4, a1);
+    rec[1] = make_float4(a3, a5, c0, c2);
+    rec[2] = make_float4(c4, c1, c3, c5);
+    rec[3] = make_float4(__uint_as_float(make_ref(lc, leaf_base, order, refs)), __uint_as_float(make_ref(rc, leaf_base, order, refs)), 0.0f, 0.0f);
+    // AABB(AABB, AABB), interval.cuh:83-88
+    float* pb = boxes + 6 * (size_t)p;
+    pb[0] = fminf(a0, c0); pb[1] = fmaxf(a1, c1);
+    pb[2] = fminf(a2, c2); pb[3] = fmaxf(a3, c3);
+    pb[4] = fminf(a4, c4); pb[5] = fmaxf(a5, c5);
+    cur = (uint32_t)p;
+    p = parent[cur];
+  }
+}
+
+} // namespace
+
+int build_lbvh(MirtScene* sc, hipStream_t stream)
+{
+  const int n = sc->N;
+  sc->built = false;
+  sc->root_ref = REF_NONE;
+  if (n == 0) { sc->built = true; sc->build_ms = 0.0f; return MIRT_OK; }   // main.cu:44: build skipped when there are no primitives
+
+  MIRT_HIP(hipEventRecord(sc->ev0, stream));
+  // scene bounds
+  static const uint32_t init_keys[6] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0u, 0u, 0u};
+  MIRT_HIP(hipMemcpyAsync(sc->bounds_keys, init_keys, sizeof(init_keys), hipMemcpyHostToDevice, stream));
+  const int nblk = (n + BLOCK - 1) / BLOCK;
+  const int bgrid = nblk < 2048 ? nblk : 2048;
+  hipLaunchKernelGGL(prim_bounds_kernel, dim3(bgrid), dim3(BLOCK), 0, stream, sc->refs_in, sc->spheres, sc->tri_verts, n, sc->bounds_keys);
+
+  // morton codes + stable sort
+  uint32_t *k0 = nullptr, *v0 = nullptr, *k1 = nullptr, *v1 = nullptr, *hist = nullptr;
+  const int sblocks = (n + SORT_TILE - 1) / SORT_TILE;
+  MIRT_HIP(hipMalloc(&k0, sizeof(uint32_t) * n)); MIRT_HIP(hipMalloc(&v0, sizeof(uint32_t) * n));
+  MIRT_HIP(hipMalloc(&k1, sizeof(uint32_t) * n)); MIRT_HIP(hipMalloc(&v1, sizeof(uint32_t) * n));
+  MIRT_HIP(hipMalloc(&hist, sizeof(uint32_t) * 256 * (size_t)sblocks));
+  hipLaunchKernelGGL(morton_kernel, dim3(nblk), dim3(BLOCK), 0, stream, sc->refs_in, sc->spheres, sc->tri_verts, n, sc->bounds_keys, k0, v0);
+  uint32_t *ki = k0, *vi = v0, *ko = k1, *vo = v1;
+  for (int pass = 0; pass < 4; ++pass) {
+    const int shift = pass * 8;
+    hipLaunchKernelGGL(radix_pass_kernel<false>, dim3(sblocks), dim3(BLOCK), 0, stream, ki, vi, ko, vo, hist, hist, n, shift, sblocks);
+    hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(1024), 0, stream, hist, 256 * sblocks);
+    hipLaunchKernelGGL(radix_pass_kernel<true>, dim3(sblocks), dim3(BLOCK), 0, stream, ki, vi, ko, vo, hist, hist, n, shift, sblocks);
+    uint32_t* t = ki; ki = ko; ko = t; t = vi; vi = vo; vo = t;
+  }
+  // after 4 passes the result is back in k0/v0
+  MIRT_HIP(hipMemcpyAsync(sc->codes, ki, sizeof(uint32_t) * n, hipMemcpyDeviceToDevice, stream));
+  MIRT_HIP(hipMemcpyAsync(sc->order, vi, sizeof(uint32_t) * n, hipMemcpyDeviceToDevice, stream));
+
+  uint32_t* arrived = nullptr;
+  if (n > 1) {
+    MIRT_HIP(hipMalloc(&arrived, sizeof(uint32_t) * (n - 1)));
+    MIRT_HIP(hipMemsetAsync(arrived, 0, sizeof(uint32_t) * (n - 1), stream));
+    MIRT_HIP(hipMemsetAsync(sc->parent, 0xff, sizeof(int) * (2 * (size_t)n - 1), stream));
+    const int kblk = (n - 1 + BLOCK - 1) / BLOCK;
+    hipLaunchKernelGGL(karras_kernel, dim3(kblk), dim3(BLOCK), 0, stream, sc->codes, n, sc->child_l, sc->child_r, sc->parent);
+  } else {
+    MIRT_HIP(hipMemsetAsync(sc->parent, 0xff, sizeof(int), stream));
+  }
+  hipLaunchKernelGGL(refit_pack_kernel, dim3(nblk), dim3(BLOCK), 0, stream, n, sc->order, sc->refs_in, sc->spheres, sc->tri_verts,
+                     sc->child_l, sc->child_r, sc->parent, arrived, sc->boxes, sc->nodes);
+  MIRT_HIP(hipGetLastError());
+  MIRT_HIP(hipEventRecord(sc->ev1, stream));
+  MIRT_HIP(hipStreamSynchronize(stream));   // lbvh_builder.cu:475
+  MIRT_HIP(hipEventElapsedTime(&sc->build_ms, sc->ev0, sc->ev1));
+
+  if (n == 1) {
+    uint32_t ord = 0;
+    MIRT_HIP(hipMemcpy(&ord, sc->order, 4, hipMemcpyDeviceToHost));
+    MirtPrimRef r;
+    MIRT_HIP(hipMemcpy(&r, sc->refs_in + ord, sizeof(r), hipMemcpyDeviceToHost));
+    sc->root_ref = REF_LEAF | (r.type ? REF_TRI : 0u) | (r.id & REF_IDMASK);
+  } else {
+    sc->root_ref = 0;
+  }
+  (void)hipFree(k0); (void)hipFree(v0); (void)hipFree(k1); (void)hipFree(v1); (void)hipFree(hist); (void)hipFree(arrived);
+  sc->built = true;
+  return MIRT_OK;
+}
+
+int get_tree(MirtScene* sc, MirtTreeNode* nodes, uint32_t* codes, MirtPrimRef* refs, float* bounds)
+{
+  const int n = sc->N;
+  if (!sc->built) { set_error("mirt_get_tree: LBVH not built"); return MIRT_ERR_STATE; }
+  if (n == 0) return MIRT_OK;
+  MIRT_HIP(hipDeviceSynchronize());
+  std::vector<uint32_t> order(n), cl(n > 1 ? n - 1 : 0), cr(n > 1 ? n - 1 : 0);
+  std::vector<MirtPrimRef> rin(n);
+  std::vector<float> boxes(6 * (2 * (size_t)n - 1));
+  MIRT_HIP(hipMemcpy(order.data(), sc->order, 4 * (size_t)n, hipMemcpyDeviceToHost));
+  MIRT_HIP(hipMemcpy(rin.data(), sc->refs_in, sizeof(MirtPrimRef) * (size_t)n, hipMemcpyDeviceToHost));
+  MIRT_HIP(hipMemcpy(boxes.data(), sc->boxes, 4 * boxes.size(), hipMemcpyDeviceToHost));
+  if (n > 1) {
+    MIRT_HIP(hipMemcpy(cl.data(), sc->child_l, 4 * (size_t)(n - 1), hipMemcpyDeviceToHost));
+    MIRT_HIP(hipMemcpy(cr.data(), sc->child_r, 4 * (size_t)(n - 1), hipMemcpyDeviceToHost));
+  }
+  if (codes) MIRT_HIP(hipMemcpy(codes, sc->codes, 4 * (size_t)n, hipMemcpyDeviceToHost));
+  if (refs) for (int i = 0; i < n; ++i) refs[i] = rin[order[i]];
+  if (nodes) {
+    for (int i = 0; i < 2 * n - 1; ++i) {
+      MirtTreeNode& t = nodes[i];
+      const float* b = &boxes[6 * (size_t)i];
+      t.xmin = b[0]; t.xmax = b[1]; t.ymin = b[2]; t.ymax = b[3]; t.zmin = b[4]; t.zmax = b[5];
+      if (i < n - 1) { t.left = cl[i]; t.right = cr[i]; t.prim_offset = 0; t.count = 0; }
+      else { t.left = 0; t.right = 0; t.prim_offset = (uint32_t)(i - (n - 1)); t.count = 1; }
+    }
+  }
+  if (bounds) {
+    uint32_t k[6];
+    MIRT_HIP(hipMemcpy(k, sc->bounds_keys, sizeof(k), hipMemcpyDeviceToHost));
+    for (int i = 0; i < 6; ++i) {
+      uint32_t u = (k[i] & 0x80000000u) ? (k[i] & 0x7fffffffu) : ~k[i];
+      memcpy(&bounds[i], &u, 4);
+    }
+  }
+  return MIRT_OK;
+}
+
+} // namespace mirt

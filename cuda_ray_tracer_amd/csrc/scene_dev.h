@@ -1,0 +1,133 @@
+// Device-resident scene (the reference's RawConfig, config.hpp:75-126) and kernel argument structs.
+#ifndef MIRT_SCENE_DEV_H
+#define MIRT_SCENE_DEV_H
+
+#include <hip/hip_runtime.h>
+#include <string>
+#include <vector>
+
+#include "../../include/mirt.h"
+#include "device_common.h"
+#include "xorwow_tables.h"
+
+namespace mirt {
+
+// child reference inside a packed node / the root reference
+//   bit 31 = leaf; leaf: bit 30 = primitive type (0 sphere, 1 triangle), bits 0..29 = index in its array
+//   internal: index of the internal node
+constexpr uint32_t REF_LEAF = 0x80000000u;
+constexpr uint32_t REF_TRI = 0x40000000u;
+constexpr uint32_t REF_IDMASK = 0x3fffffffu;
+constexpr uint32_t REF_NONE = 0xffffffffu;   // empty scene / plane marker is separate
+
+struct PlaneDev { float nx, ny, nz, px, py, pz; float mat[11]; float pad; };   // 72 B
+struct LightDev { float x, y, z, r, g, b; };                                    // suns: direction; bulbs: position
+
+// Arguments of the trace kernel (passed by value in the kernarg segment: uniform, scalar loads)
+struct RenderArgs {
+  // frame / camera (RawConfig scalars)
+  int width, height, bounces, spp, gi;
+  int fisheye, panorama;
+  float dof_focus, dof_lens, expose;
+  f3 forward, right, up, eye;
+  // partition (MirtRenderParams)
+  int stripe_rows, num_parts, part;
+  long long num_local_pixels;
+  long long num_samples;          // num_local_pixels * max(spp,1)
+  // geometry
+  const float4* nodes;            // 4 x float4 per internal node
+  const float4* spheres;          // (cx,cy,cz,r)
+  const float4* tris;             // 3 x float4: p0.xyz nor.x | nor.yz e1.xy | e1.z e2.xyz
+  const float4* mats;             // 3 x float4 per primitive: spheres first, then triangles
+  uint32_t root_ref;
+  int num_spheres;
+  int num_prims;
+  const PlaneDev* planes; int num_planes;
+  const LightDev* suns; int num_suns;
+  const LightDev* bulbs; int num_bulbs;
+  // rng
+  RngTablesDev rng;
+  int needs_rng;
+  // outputs / workspace
+  float4* samples;                // one RGBA per sample
+  uint32_t* stack_spill;          // [STACK_TOTAL - STACK_LDS][grid threads]
+  float* pending;                 // [pending_slots][16 words][grid threads] or null
+  int pending_slots;
+  unsigned long long* counters;   // MirtStats head (8 x u64) or null
+};
+
+struct ResolveArgs {
+  const float4* samples;
+  unsigned char* rgba8;
+  float4* rgba_f32;               // nullable
+  long long num_local_pixels;
+  int spp;
+};
+
+// device copies of the skip-ahead tables, keyed by spp (spp > 1) or by -(frame pixels) (spp <= 1)
+struct RngCache {
+  RngTables host;
+  long long key = -1;
+  uint4* A = nullptr; uint32_t* B = nullptr; uint32_t* K = nullptr; uint32_t* R2 = nullptr;
+};
+
+} // namespace mirt
+
+struct MirtScene {
+  int device = 0;
+  MirtSceneDesc d{};
+  int N = 0, Ns = 0, Nt = 0;
+  // uploaded geometry
+  float4* spheres = nullptr;
+  float4* tris = nullptr;
+  float4* mats = nullptr;
+  MirtPrimRef* refs_in = nullptr;       // file order
+  float4* tri_verts = nullptr;          // 3 x float4 per triangle (p0,p1,p2) -- build only
+  mirt::PlaneDev* planes = nullptr;
+  mirt::LightDev* suns = nullptr;
+  mirt::LightDev* bulbs = nullptr;
+  // build products
+  uint32_t* codes = nullptr;            // sorted Morton codes [N]
+  uint32_t* order = nullptr;            // sorted position -> file-order index [N]
+  uint32_t* child_l = nullptr;          // reference numbering [N-1]
+  uint32_t* child_r = nullptr;
+  int* parent = nullptr;                // [2N-1]
+  float* boxes = nullptr;               // [2N-1][6] xmin,xmax,ymin,ymax,zmin,zmax
+  float4* nodes = nullptr;              // packed [N-1][4]
+  uint32_t* bounds_keys = nullptr;      // [6] ordered-uint min xyz, max xyz
+  uint32_t root_ref = mirt::REF_NONE;
+  bool built = false;
+  float build_ms = 0.0f;
+  // render workspace
+  float4* samples = nullptr; size_t samples_cap = 0;
+  uint32_t* stack_spill = nullptr; size_t spill_cap = 0;
+  float* pending = nullptr; size_t pending_cap = 0;
+  unsigned long long* counters = nullptr;  // 8 x u64 on device
+  // rng tables cache
+  mirt::RngCache rng;
+  // timing
+  hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr, ev3 = nullptr;
+  hipStream_t last_stream = nullptr;
+  bool have_render = false;
+  bool last_counted = false;
+  bool any_trans = false;                  // some material has transparency != 0
+  bool any_rough = false;
+};
+
+namespace mirt {
+int hip_fail(hipError_t e, const char* what, const char* file, int line);
+// lbvh_build.hip
+int build_lbvh(MirtScene* sc, hipStream_t stream);
+int get_tree(MirtScene* sc, MirtTreeNode* nodes, uint32_t* codes, MirtPrimRef* refs, float* bounds);
+// render.hip
+int render(MirtScene* sc, const MirtRenderParams* p, void* d_rgba8, void* d_rgba_f32, hipStream_t stream);
+int scatter_part(const MirtRenderParams* p, const void* d_part, void* d_frame, hipStream_t stream);
+int64_t render_num_pixels(const MirtRenderParams* p);
+int probe_math(int device, int which, int n, const float* in, float* out);
+int probe_xorwow(int device, int spp, int nstreams, int draws, uint32_t* out);
+int ensure_rng_tables(RngCache* rc, int spp, long long frame_pixels, hipStream_t stream, RngTablesDev* out);
+void rng_cache_free(RngCache* rc);
+}
+#define MIRT_HIP(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) return mirt::hip_fail(e_, #call, __FILE__, __LINE__); } while (0)
+
+#endif

@@ -1,0 +1,158 @@
+/*
+ * mirt.h -- C ABI of libmirt.so, the MI355X-native replacement for the hot path of
+ * GJ0407790/cuda_ray_tracer (LBVH build + BVH-traversal render).
+ *
+ * Every entry point names the reference interface it replaces (paths relative to the reference
+ * tree).  Plain C: opaque handles, POD structs, pointers and sizes; no C++ or torch types.
+ * All functions return 0 on success and a non-zero MirtStatus otherwise; mirt_last_error() returns a
+ * thread-local description.  The library never calls exit() (the reference's CUDA_CHECK does,
+ * main.cu:14-23); the CLI maps a non-zero status to the reference's message + exit code.
+ *
+ * Device pointers are ordinary HIP device pointers (hipMalloc, or torch tensor data_ptr()).
+ * `stream` is a hipStream_t passed as void* (NULL = the default stream).  A MirtScene is bound to the
+ * HIP device it was created on and is not thread-safe; render calls are asynchronous on `stream`
+ * unless stated otherwise.  There is no CPU fallback: without a HIP device scene creation fails.
+ */
+#ifndef MIRT_H
+#define MIRT_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MIRT_VERSION 1
+
+typedef enum MirtStatus {
+  MIRT_OK = 0,
+  MIRT_ERR_IO = 1,          /* "Error opening file..."            parse.cpp:22-25 */
+  MIRT_ERR_PARSE = 2,       /* "One of the lines are not valid."  parse.cpp:218-221 */
+  MIRT_ERR_ARG = 3,
+  MIRT_ERR_HIP = 4,         /* any HIP runtime failure (CUDA_CHECK, main.cu:14-23) */
+  MIRT_ERR_NO_DEVICE = 5,
+  MIRT_ERR_STATE = 6        /* e.g. render before build */
+} MirtStatus;
+
+/* ---- POD scene structs: same field order and size as the reference's classes -------------------- */
+typedef struct MirtVec3 { float x, y, z; } MirtVec3;                       /* vec3.cuh:21-92, 12 B */
+typedef struct MirtRGB { float r, g, b; } MirtRGB;                         /* struct.cuh:11-34, 12 B */
+typedef struct MirtMaterials {                                             /* object.cuh:17-38, 44 B */
+  MirtRGB color, shininess, trans;
+  float ior, roughness;
+} MirtMaterials;
+typedef struct MirtSphere { MirtVec3 c; float r; MirtMaterials mat; } MirtSphere;            /* object.cuh:95-119, 60 B */
+typedef struct MirtTriangle { MirtVec3 p0, p1, p2, nor, e1, e2; MirtMaterials mat; } MirtTriangle; /* object.cuh:165-194, 116 B */
+typedef struct MirtPlane { float a, b, c, d; MirtVec3 nor, point; MirtMaterials mat; } MirtPlane;  /* object.cuh:124-149, 84 B */
+typedef struct MirtSun { MirtVec3 dir; MirtRGB color; } MirtSun;           /* object.cuh:232-248, 24 B */
+typedef struct MirtBulb { MirtVec3 point; MirtRGB color; } MirtBulb;       /* object.cuh:250-266, 24 B */
+typedef struct MirtPrimRef { uint32_t type; uint32_t id; } MirtPrimRef;    /* object.cuh:72-88, 8 B; 0 sphere, 1 triangle */
+
+/* Scalars of StlConfig/RawConfig (config.hpp:24-73, 75-126) + host arrays in file order.
+ * Pointers are borrowed for the duration of the call that takes the descriptor. */
+typedef struct MirtSceneDesc {
+  int32_t width, height, bounces, aa;
+  float dof_focus, dof_lens;
+  MirtVec3 forward, right, up, eye;
+  float expose;                       /* +inf = exposure off (config.hpp:50) */
+  int32_t fisheye, panorama, gi;
+  int32_t num_spheres, num_triangles, num_prims, num_planes, num_suns, num_bulbs;
+  const MirtSphere* spheres;
+  const MirtTriangle* triangles;
+  const MirtPrimRef* prim_refs;       /* host_primitive_references, config.hpp:64 */
+  const MirtPlane* planes;
+  const MirtSun* suns;
+  const MirtBulb* bulbs;
+} MirtSceneDesc;
+
+typedef struct MirtHostScene MirtHostScene;   /* parsed scene on the host  (StlConfig, config.hpp:24-73) */
+typedef struct MirtScene MirtScene;           /* device-resident scene     (RawConfig, config.hpp:75-126) */
+
+const char* mirt_last_error(void);
+int mirt_version(void);
+
+/* ---- scene front end -------------------------------------------------------------------------- */
+/* parseInput(argv, StlConfig&), parse.hpp:10 / parse.cpp:16-39.  Same grammar (parse.cpp:41-222). */
+int mirt_parse_scene_file(const char* path, MirtHostScene** out);
+int mirt_parse_scene_text(const char* text, size_t len, MirtHostScene** out);
+/* Deterministic synthetic scene of BASELINE config 5; not in the reference. */
+int mirt_synthetic_scene(uint64_t seed, int num_spheres, int num_triangles, MirtHostScene** out);
+void mirt_host_scene_destroy(MirtHostScene* hs);
+int mirt_host_scene_desc(const MirtHostScene* hs, MirtSceneDesc* out);   /* pointers stay owned by hs */
+const char* mirt_host_scene_filename(const MirtHostScene* hs);           /* the `png W H name` name, parse.cpp:47-51 */
+
+/* ---- device scene ----------------------------------------------------------------------------- */
+/* initRawConfigFromStl + copyConfigDataToDevice, config_utils.cuh:11-17 / config_utils.cu:18-199.
+ * Uploads the scene to HIP device `device` in the SoA layout of DESIGN.md. */
+int mirt_scene_create(const MirtSceneDesc* desc, int device, MirtScene** out);
+/* freeRawConfigDeviceMemory, config_utils.cuh:20 (frees everything; the reference leaks the SoA arrays). */
+void mirt_scene_destroy(MirtScene* sc);
+
+/* build_lbvh_karas(RawConfig&, int morton_bits), lbvh_builder.cuh:14 / lbvh_builder.cu:401-521:
+ * scene bounds -> 30-bit Morton codes -> stable radix sort -> Karras hierarchy -> AABB refit -> 64-byte
+ * two-child node records.  Synchronous (like the reference, lbvh_builder.cu:475).  build_ms (nullable)
+ * receives the device time measured with HIP events (the reference prints it, lbvh_builder.cu:489). */
+int mirt_build_lbvh(MirtScene* sc, void* stream, float* build_ms);
+
+/* ---- render ----------------------------------------------------------------------------------- */
+#define MIRT_RENDER_COUNTERS 1u   /* also count rays / node visits / leaf tests (slower kernel variant) */
+
+/* The frame is cut into horizontal stripes of `stripe_rows` rows; stripe i belongs to part
+ * (i % num_parts).  A call renders the stripes of part `part` into a compact buffer (the part's stripes
+ * in increasing order, each row-major).  num_parts = 1, part = 0 renders the whole frame row-major. */
+typedef struct MirtRenderParams {
+  int32_t width, height;     /* frame size (RawConfig::width/height) */
+  int32_t spp;               /* the reference's `aa`: 0 = one un-jittered sample, 1 = one jittered, >1 = spp samples */
+  int32_t stripe_rows, num_parts, part;
+  uint32_t flags;
+} MirtRenderParams;
+
+/* number of pixels the call writes */
+int64_t mirt_render_num_pixels(const MirtRenderParams* p);
+
+/* render(pixel_t* d_image, w, h, aa, RawConfig*), draw.cuh:10 / draw.cu:215-239.
+ * d_rgba8: num_pixels * 4 bytes, RGBA (pixel_t, libpng.h:23-27).  d_rgba_f32 (nullable): num_pixels * 4
+ * floats, the linear RGBA sample mean before sRGB/quantisation (for parity checks). */
+int mirt_render(MirtScene* sc, const MirtRenderParams* p, void* d_rgba8, void* d_rgba_f32, void* stream);
+
+/* Scatter a compact part buffer back into a full row-major frame (device to device). */
+int mirt_scatter_part(const MirtRenderParams* p, const void* d_part_rgba8, void* d_frame_rgba8, void* stream);
+
+typedef struct MirtStats {
+  /* filled by a render with MIRT_RENDER_COUNTERS */
+  uint64_t samples, rays, shadow_rays, internal_visits, sphere_tests, tri_tests, mat_fetches, max_stack;
+  /* device time of the last render's trace kernel and of the whole render call, HIP events, ms */
+  float trace_kernel_ms, render_ms;
+  float build_ms;
+  int32_t num_nodes;
+} MirtStats;
+/* Waits for the last render on its stream, then reports. */
+int mirt_get_stats(MirtScene* sc, MirtStats* out);
+
+/* ---- introspection for parity tests ----------------------------------------------------------- */
+typedef struct MirtTreeNode {      /* the reference's LBVHNode (lbvh.cuh:6-28), flattened */
+  float xmin, xmax, ymin, ymax, zmin, zmax;
+  uint32_t left, right, prim_offset, count;
+} MirtTreeNode;
+/* Copies the tree back in the reference's numbering: internal nodes [0,N-2], leaves [N-1,2N-2].
+ * nodes: 2N-1 entries; codes: N sorted Morton codes; refs: N sorted primitive references;
+ * bounds: 6 floats (min xyz, max xyz).  Any pointer may be NULL. */
+int mirt_get_tree(MirtScene* sc, MirtTreeNode* nodes, uint32_t* codes, MirtPrimRef* refs, float* bounds);
+
+/* Device-side probes of the arithmetic the kernels use (which: 0 logf 1 expf 2 sinf 3 cosf 4 pow(x,1/2.4)
+ * 5 RGBtosRGB 6 sqrtf 7 1/x), and of the XORWOW generator. */
+int mirt_probe_math(int device, int which, int n, const float* host_in, float* host_out);
+/* Stream i of num_streams is seeded exactly as the trace kernel seeds it: spp > 1: pixel i / spp, sample i % spp
+ * (curand_init(1234 + pixel, sample, 0), draw.cu:162); spp <= 1: pixel i (curand_init(1234, pixel, 0), draw.cu:105).
+ * host_out[i * draws + k] is the k-th raw 32-bit output. */
+int mirt_probe_xorwow(int device, int spp, int num_streams, int draws, uint32_t* host_out);
+
+/* ---- output ----------------------------------------------------------------------------------- */
+/* Image::save, libpng.cpp:73-107: 8-bit RGBA, non-interlaced PNG (own encoder; zlib only). */
+int mirt_write_png(const char* path, const uint8_t* rgba, int width, int height);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MIRT_H */
