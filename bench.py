@@ -1,0 +1,175 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the MI355X ray tracer.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--scene tenthousand] [--width 1920 --height 1080 --spp 16]
+
+One step = one frame of the hot path (trace + resolve, scene and BVH resident in HBM, synthetic-free bundled scene):
+BASELINE.json's headline workload, `tenthousand.txt` at 1920x1080, 16 samples per pixel.  With N > 1 (launched by
+torch.distributed.run, one process per GPU) the frame is cut into interleaved row stripes, every rank renders its
+stripes with a replicated BVH, and the 8-bit framebuffer is gathered to rank 0 over RCCL and re-interleaved there; the
+total work per frame is fixed ("strong" scaling).  Rank 0 prints ONE JSON line.
+
+value        = rays of the whole frame / max-over-ranks wall time per frame  (Mrays/s; a ray = one hitNearest call with
+               bounce != 0), counted by the kernel's counters variant in an untimed pass.
+roofline     = algorithmic bytes of rank 0's trace-kernel launch (64 B per internal-node visit + 16 B per sphere test
+               + 48 B per triangle test + 44 B per material fetch, all counted) / its mean duration from HIP events on
+               the launch stream, against 8 TB/s HBM.
+cpu_baseline = the CPU oracle (oracle/, a port of the reference's algorithm) on one host core over a bounded
+               sub-sample of the same workload (every `step`-th pixel in x and y), N = 1 only.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0   # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def algorithmic_bytes(st):
+    return st["internal_visits"] * 64 + st["sphere_tests"] * 16 + st["tri_tests"] * 48 + st["mat_fetches"] * 44
+
+
+def cpu_baseline(scene_file, width, height, spp, step):
+    """Times the oracle (test infrastructure, used here only as the reported CPU baseline) on one core."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib
+    import pyscene
+    o = oracle_lib.OracleScene(pyscene.parse_file(scene_file), bounds_mode=0)
+    t0 = time.perf_counter()
+    st, _ = o.render_subsample(width, height, spp, step, flags=0, nthreads=1)
+    dt = time.perf_counter() - t0
+    o.close()
+    return {"value": st["rays"] / dt / 1e6, "unit": "Mrays/s", "cores": 1, "kind": "port",
+            "sample": f"every {step}th pixel in x and y of the {width}x{height} frame at {spp} spp "
+                      f"({st['samples']} samples, {st['rays']} rays, {dt:.1f} s, full nearest-hit shadow rays as in the reference)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--scene", default="tenthousand")
+    ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--spp", type=int, default=16)
+    ap.add_argument("--stripe-rows", type=int, default=4)
+    ap.add_argument("--cpu-step", type=int, default=3, help="sub-sampling step of the CPU baseline (0 = skip)")
+    ap.add_argument("--png", default=None, help="write the last frame here (rank 0)")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    import cuda_ray_tracer_amd as m
+    from cuda_ray_tracer_amd import api
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("bench.py --gpus N > 1 must be launched with torch.distributed.run (one process per GPU)")
+        args.gpus = world
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the product has no CPU path")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    scene_file = os.path.join(ROOT, "scenes", args.scene + ".txt")
+    W, H, SPP = args.width, args.height, args.spp
+    stl = m.parseInput(scene_file)
+    raw = m.initRawConfigFromStl(stl, local_rank)       # BVH replicated: every rank builds the identical tree
+    build_ms = m.build_lbvh_karas(raw)
+
+    from cuda_ray_tracer_amd.tiles import StripePartition, FrameGatherer
+    stripe_rows = args.stripe_rows if world > 1 else H
+    partition = StripePartition(W, H, stripe_rows, world)
+    mine = partition.params(rank, SPP)
+    gatherer = FrameGatherer(partition, rank, world, dev)
+    part = gatherer.new_part_buffer(dev)
+
+    def step():
+        m.render(part, W, H, SPP, raw, params=mine)
+        if world > 1:
+            return gatherer.gather(part)     # RCCL gather over xGMI (<= 1.04 MB per rank at 1080p) + re-interleave on rank 0
+        return part                          # N = 1: the part already is the whole row-major frame
+
+    # untimed counting pass (same rays every frame: the RNG is keyed by pixel and sample index only)
+    cparams = partition.params(rank, SPP, counters=True)
+    m.render(part, W, H, SPP, raw, params=cparams)
+    torch.cuda.synchronize()
+    cst = raw.stats()
+    counts = torch.tensor([cst[k] for k in ("rays", "internal_visits", "sphere_tests", "tri_tests", "mat_fetches", "samples")],
+                          dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(counts)
+    total_rays = float(counts[0].item())
+
+    for _ in range(args.warmup):
+        step()
+    kernel_ms = []
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+        kernel_ms.append(raw.stats()["trace_kernel_ms"])   # HIP events around the trace kernel on its launch stream
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = float(tmax.item())
+
+    if rank == 0:
+        ms_per_step = dt / args.steps * 1e3
+        mean_kernel_ms = sum(kernel_ms) / len(kernel_ms)
+        my_bytes = algorithmic_bytes(cst)
+        achieved = my_bytes / (mean_kernel_ms * 1e-3) / 1e9
+        out = {
+            "metric": "Mrays/sec, tenthousand.txt 1080p@16spp" if (args.scene, W, H, SPP) == ("tenthousand", 1920, 1080, 16)
+                      else f"Mrays/sec, {args.scene}.txt {W}x{H}@{SPP}spp",
+            "value": total_rays * args.steps / dt / 1e6,
+            "unit": "Mrays/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms_per_step,
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "bundled scene file scenes/%s.txt (the reference's own input); no synthetic substitution" % args.scene,
+            "config": {"workload": f"{args.scene}.txt {W}x{H} {SPP}spp", "rays_per_frame": int(total_rays),
+                       "samples_per_frame": int(counts[5].item()), "parallelism": f"image stripes x{world}" if world > 1 else "single GPU",
+                       "stripe_rows": stripe_rows, "lbvh_build_ms": build_ms},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": None, "kernel": "trace_kernel", "kernel_ms": mean_kernel_ms,
+                         "algorithmic_bytes_per_launch": int(my_bytes),
+                         "per_ray": {"internal_visits": cst["internal_visits"] / max(cst["rays"], 1),
+                                     "sphere_tests": cst["sphere_tests"] / max(cst["rays"], 1),
+                                     "tri_tests": cst["tri_tests"] / max(cst["rays"], 1)}},
+        }
+        if world == 1 and args.cpu_step > 0:
+            out["cpu_baseline"] = cpu_baseline(scene_file, W, H, SPP, args.cpu_step)
+        else:
+            out["cpu_baseline"] = None
+        if args.png:
+            m.write_png(args.png, step()[: W * H * 4].cpu().numpy(), W, H)
+        print(json.dumps(out), flush=True)
+
+    raw.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

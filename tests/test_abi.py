@@ -1,0 +1,95 @@
+"""The C-ABI library loads and exports every symbol include/mirt.h declares; host-only entry points behave.
+No compute calls are made here (no GPU in this container)."""
+import ctypes as C
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+import cuda_ray_tracer_amd as m
+from cuda_ray_tracer_amd import api
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    txt = open(os.path.join(ROOT, "include", "mirt.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(mirt_[a-z0-9_]+)\s*\(", txt)))
+
+
+def test_library_exports_every_declared_symbol():
+    L = m.lib()
+    syms = declared_symbols()
+    assert len(syms) >= 19
+    for s in syms:
+        assert hasattr(L, s), s
+    assert sorted(api.EXPORTS) == syms
+    assert L.mirt_version() == 1
+
+
+def test_exported_symbols_are_unmangled_c():
+    out = subprocess.check_output(["nm", "-D", "--defined-only", api.LIB_PATH]).decode()
+    names = {line.split()[-1] for line in out.splitlines() if line.strip()}
+    for s in declared_symbols():
+        assert s in names, s
+
+
+def test_pod_struct_sizes_match_the_reference_layout():
+    assert C.sizeof(api.SceneDesc) == 4 * 4 + 2 * 4 + 4 * 12 + 4 + 3 * 4 + 6 * 4 + 6 * 8
+    assert C.sizeof(api.RenderParams) == 28
+    assert C.sizeof(api.TreeNode) == 40
+
+
+@pytest.mark.parametrize("w,h,rows,parts", [(1920, 1080, 4, 8), (200, 121, 8, 2), (50, 7, 5, 3), (17, 9, 4, 8), (64, 36, 36, 1)])
+def test_stripe_partition_covers_the_frame_exactly_once(w, h, rows, parts):
+    from cuda_ray_tracer_amd.tiles import StripePartition
+    sp = StripePartition(w, h, rows, parts)
+    seen = np.zeros(h, np.int32)
+    for p in range(parts):
+        n = api.num_pixels(api.render_params(w, h, 16, rows, parts, p))
+        assert n == sp.num_pixels(p)
+        for r in sp.rows(p):
+            seen[r] += 1
+    assert np.all(seen == 1)
+
+
+def test_bad_render_params_are_rejected():
+    assert m.lib().mirt_render_num_pixels(C.byref(api.render_params(10, 10, 1, 4, 2, 2))) == -1
+    assert m.lib().mirt_render_num_pixels(C.byref(api.render_params(0, 10, 1, 4, 1, 0))) == -1
+
+
+def test_png_writer_roundtrip(tmp_path):
+    from PIL import Image
+    rng = np.random.default_rng(0)
+    img = rng.integers(0, 256, (37, 53, 4), dtype=np.uint8)
+    path = str(tmp_path / "x.png")
+    m.write_png(path, img, 53, 37)
+    back = np.array(Image.open(path))
+    assert back.shape == (37, 53, 4) and np.array_equal(back, img)
+
+
+def test_product_fails_loudly_without_a_gpu():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    stl = m.parseText("png 4 4 a.png\nsphere 0 0 -1 1\n")
+    with pytest.raises(m.MirtError) as e:
+        m.initRawConfigFromStl(stl, 0)
+    assert e.value.status == 5 and "no CPU path" in e.value.message
+
+
+def test_product_does_not_reference_the_oracle():
+    """The product tree must not include, link or load anything under oracle/."""
+    pkg = os.path.join(ROOT, "cuda_ray_tracer_amd")
+    for dirpath, _, files in os.walk(pkg):
+        if "_build" in dirpath or "__pycache__" in dirpath:
+            continue
+        for f in files:
+            if f.endswith((".py", ".cpp", ".h", ".hip")):
+                txt = open(os.path.join(dirpath, f)).read()
+                assert "oracle" not in txt.lower() or f == "build.py" and False, os.path.join(dirpath, f)
+    needed = subprocess.check_output(["objdump", "-p", api.LIB_PATH]).decode()
+    assert "liboracle" not in needed

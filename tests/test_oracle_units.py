@@ -1,0 +1,166 @@
+"""Unit tests of the oracle's parts (no GPU): RNG, deterministic math, LBVH validity, invariances."""
+import os
+import re
+
+import numpy as np
+import pytest
+
+import oracle_lib as ol
+
+
+# ---------------------------------------------------------------- XORWOW ----
+def _step(v):
+    t = (v[0] ^ (v[0] >> 2)) & 0xFFFFFFFF
+    v = [v[1], v[2], v[3], v[4], ((v[4] ^ (v[4] << 4)) ^ (t ^ (t << 1))) & 0xFFFFFFFF]
+    return v
+
+
+def test_xorwow_seeding_and_stepping_follow_the_published_algorithm():
+    seed = 1234
+    s0 = (seed & 0xFFFFFFFF) ^ 0xaad26b49
+    s1 = (seed >> 32) ^ 0xf7dcefdd
+    t0 = (1099087573 * s0) & 0xFFFFFFFF
+    t1 = (2591861531 * s1) & 0xFFFFFFFF
+    d = (6615241 + t1 + t0) & 0xFFFFFFFF
+    v = [(123456789 + t0) & 0xFFFFFFFF, 362436069 ^ t0, (521288629 + t1) & 0xFFFFFFFF, 88675123 ^ t1, (5783321 + t0) & 0xFFFFFFFF]
+    want = []
+    for _ in range(8):
+        v = _step(v)
+        d = (d + 362437) & 0xFFFFFFFF
+        want.append((v[4] + d) & 0xFFFFFFFF)
+    got = np.zeros(8, np.uint32)
+    ol.lib().orc_xorwow_seq(seed, 0, 0, 8, got.ctypes.data)
+    assert got.tolist() == want
+
+
+def test_sequence_jump_matrix_equals_rocrands_precomputed_table():
+    """The recurrence and the 2^67 jump are the same in rocRAND (only seeding/uniform mapping differ), so its
+    precomputed matrix cross-checks the oracle's own 67 squarings."""
+    hdr = "/opt/rocm/include/rocrand/rocrand_xorwow_precomputed.h"
+    if not os.path.exists(hdr):
+        pytest.skip("rocRAND header not present")
+    txt = open(hdr).read()
+    m = re.search(r"h_xorwow_sequence_jump_matrices\s*\[[^\]]*\]\s*\[[^\]]*\]\s*=\s*\{\s*\{(.*?)\}", txt, re.S)
+    assert m, "table not found"
+    vals = np.array([int(x, 0) for x in re.findall(r"0x[0-9a-fA-F]+|\d+", m.group(1))][:800], dtype=np.uint32)
+    mine = np.zeros(800, np.uint32)
+    ol.lib().orc_jump_matrix(0, mine.ctypes.data)       # column-major: col[word i*32 + bit j][k]
+    assert np.array_equal(mine, vals)
+
+
+def test_subsequence_jumps_compose():
+    st = lambda sub: (lambda a: (ol.lib().orc_xorwow_state(99, sub, a.ctypes.data), a)[1])(np.zeros(6, np.uint32))
+    a, b = st(5), st(12)
+    assert not np.array_equal(a, b)
+    # jump(5) then jump(7) == jump(12): apply matrix pow2 decomposition manually through the API
+    cols = np.zeros((160, 5), np.uint32)
+
+    def apply(k, v):
+        ol.lib().orc_jump_matrix(k, cols.ctypes.data)
+        out = np.zeros(5, np.uint32)
+        for w in range(5):
+            for bit in range(32):
+                if (int(v[w]) >> bit) & 1:
+                    out ^= cols[w * 32 + bit]
+        return out
+    v = a[:5].copy()
+    for k in (0, 1, 2):          # 7 = 1 + 2 + 4
+        v = apply(k, v)
+    assert np.array_equal(v, b[:5]) and a[5] == b[5]
+
+
+def test_uniform_and_normal_ranges():
+    out = np.zeros(20000 + 20000, np.float32)
+    ol.lib().orc_xorwow_floats(1234, 3, 20000, 20000, out.ctypes.data)
+    u, n = out[:20000], out[20000:]
+    assert u.min() > 0.0 and u.max() <= 1.0 and abs(u.mean() - 0.5) < 0.01
+    assert abs(n.mean()) < 0.03 and abs(n.std() - 1.0) < 0.03
+
+
+# ------------------------------------------------------- deterministic math ----
+@pytest.mark.parametrize("which,fn,lo,hi", [(0, np.log, 1e-10, 10.0), (1, np.exp, -40.0, 10.0), (2, np.sin, -7.0, 7.0), (3, np.cos, -7.0, 7.0),
+                                            (4, lambda x: np.power(x, float(np.float32(1) / np.float32(2.4))), 0.0, 4.0), (6, np.sqrt, 0.0, 1e6)])
+def test_math_is_within_one_ulp_of_float64_reference(which, fn, lo, hi):
+    x = np.random.default_rng(which).uniform(lo, hi, 200000).astype(np.float32)
+    got = np.zeros_like(x)
+    ol.lib().orc_math_probe(which, x.size, x.ctypes.data, got.ctypes.data)
+    want = fn(x.astype(np.float64))
+    ulp = np.spacing(np.abs(want).astype(np.float32)).astype(np.float64)
+    err = np.abs(got.astype(np.float64) - want) / np.maximum(ulp, 1e-300)
+    assert err.max() <= 0.51, err.max()
+
+
+def test_srgb_curve_endpoints():
+    x = np.array([-1.0, 0.0, 0.0031307, 0.0031308, 0.5, 1.0, 2.0, np.nan, np.inf], np.float32)
+    y = np.zeros_like(x)
+    ol.lib().orc_math_probe(5, x.size, x.ctypes.data, y.ctypes.data)
+    assert y[0] == 0 and y[1] == 0 and abs(y[5] - 1.0) < 1e-6 and y[6] == 1.0 and y[7] == 0.0 and y[8] == 1.0
+    assert abs(y[4] - 0.7353569) < 1e-6
+
+
+# ----------------------------------------------------------------- LBVH ----
+@pytest.mark.parametrize("name", ["tri", "redchair", "spiral", "tenthousand"])
+def test_tree_is_a_valid_bvh(name, oracle_scenes):
+    o = oracle_scenes(name)
+    nd, codes, n = o.nodes(), o.codes(), o.n
+    assert len(nd) == 2 * n - 1
+    assert np.all(np.diff(codes.astype(np.int64)) >= 0)
+    seen = np.zeros(2 * n - 1, np.int32)
+    stack = [0]
+    depth = {0: 0}
+    while stack:
+        i = stack.pop()
+        seen[i] += 1
+        if nd[i]["count"] == 0:
+            for c in (int(nd[i]["left"]), int(nd[i]["right"])):
+                assert nd[c]["xmin"] >= nd[i]["xmin"] and nd[c]["xmax"] <= nd[i]["xmax"]
+                assert nd[c]["ymin"] >= nd[i]["ymin"] and nd[c]["ymax"] <= nd[i]["ymax"]
+                assert nd[c]["zmin"] >= nd[i]["zmin"] and nd[c]["zmax"] <= nd[i]["zmax"]
+                depth[c] = depth[i] + 1
+                stack.append(c)
+    assert np.all(seen == 1)                       # every node reached exactly once
+    assert sorted(int(x) for x in nd[n - 1:]["prim_offset"]) == list(range(n))
+    assert max(depth.values()) < 64
+
+
+def test_duplicate_morton_codes_keep_file_order(oracle_scenes):
+    """thrust::sort_by_key is stable (lbvh_utils.cu:110); spiral.txt has duplicate codes."""
+    o = oracle_scenes("spiral")
+    codes, refs = o.codes(), o.refs()
+    dup = np.flatnonzero(codes[1:] == codes[:-1])
+    assert len(dup) > 0
+    assert np.all(refs["id"][dup + 1] > refs["id"][dup])
+
+
+def test_morton_code_corners():
+    mn, mx = np.zeros(3, np.float32), np.ones(3, np.float32)
+    f = lambda x, y, z: ol.lib().orc_morton(x, y, z, mn.ctypes.data, mx.ctypes.data)
+    assert f(0, 0, 0) == 0 and f(1, 1, 1) == 0x3FFFFFFF
+    assert f(1, 0, 0) == 0x09249249 and f(0, 1, 0) == 0x12492492 and f(0, 0, 1) == 0x24924924
+    assert f(-5, 9, 0.5) == (0x12492492 | (0x24924924 & ol.lib().orc_morton(0, 0, 0.5, mn.ctypes.data, mx.ctypes.data)))
+
+
+# ----------------------------------------------------------- invariances ----
+@pytest.mark.parametrize("name,spp", [("tenthousand", 16), ("redchair", 32), ("spiral", 1)])
+def test_any_hit_shadow_rays_give_the_same_image(name, spp, oracle_scenes):
+    o = oracle_scenes(name)
+    a = o.render(64, 36, spp, nthreads=8)
+    b = o.render(64, 36, spp, flags=ol.FLAG_ANYHIT_SHADOW, nthreads=8)
+    assert np.array_equal(a["f32"].view(np.uint32), b["f32"].view(np.uint32))
+    assert a["stats"]["rays"] == b["stats"]["rays"]
+    assert b["stats"]["internal_visits"] < a["stats"]["internal_visits"]
+
+
+def test_tiles_and_threads_do_not_change_pixels(oracle_scenes):
+    o = oracle_scenes("tenthousand")
+    whole = o.render(50, 30, 16, nthreads=1)["f32"]
+    parts = np.zeros_like(whole)
+    for (x0, y0, tw, th) in [(0, 0, 20, 30), (20, 0, 30, 11), (20, 11, 30, 19)]:
+        parts[y0:y0 + th, x0:x0 + tw] = o.render(50, 30, 16, tile=(x0, y0, tw, th), nthreads=8)["f32"]
+    assert np.array_equal(whole.view(np.uint32), parts.view(np.uint32))
+
+
+def test_struct_sizes_match_the_reference():
+    want = {0: 44, 1: 60, 2: 116, 3: 84, 4: 24, 5: 8}
+    for k, v in want.items():
+        assert ol.lib().orc_sizeof(k) == v
