@@ -33,6 +33,21 @@ def algorithmic_bytes(st):
     return st["internal_visits"] * 64 + st["sphere_tests"] * 16 + st["tri_tests"] * 48 + st["mat_fetches"] * 44
 
 
+def measured_traffic(workload):
+    """HBM bytes per trace-kernel launch from the committed rocprofv3 PMC passes (FETCH_SIZE x2 + WRITE_SIZE, see
+    profiles/*traffic*.json); bench.py cannot run the profiler on itself, so this is the last profiled value or None."""
+    import glob
+    best = None
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*traffic*.json"))):
+        try:
+            d = json.load(open(f))
+        except Exception:
+            continue
+        if d.get("workload") == workload:
+            best = d.get("hbm_bytes_per_launch")
+    return best
+
+
 def cpu_baseline(scene_file, width, height, spp, step):
     """Times the oracle (test infrastructure, used here only as the reported CPU baseline) on one core."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -152,7 +167,7 @@ def main():
                        "samples_per_frame": int(counts[5].item()), "parallelism": f"image stripes x{world}" if world > 1 else "single GPU",
                        "stripe_rows": stripe_rows, "lbvh_build_ms": build_ms},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": None, "kernel": "trace_kernel", "kernel_ms": mean_kernel_ms,
+                         "traffic": measured_traffic(f"{args.scene}.txt {W}x{H} {SPP}spp") if world == 1 else None, "kernel": "trace_kernel", "kernel_ms": mean_kernel_ms,
                          "algorithmic_bytes_per_launch": int(my_bytes),
                          "per_ray": {"internal_visits": cst["internal_visits"] / max(cst["rays"], 1),
                                      "sphere_tests": cst["sphere_tests"] / max(cst["rays"], 1),

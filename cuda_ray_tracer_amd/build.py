@@ -47,12 +47,16 @@ def build(force=False, verbose=False):
     os.makedirs(OUT, exist_ok=True)
     hipcc = _hipcc()
     deps = _all_deps()
+    extra = []
+    for var in ("MIRT_WAVES_PER_SIMD", "MIRT_STACK_LDS"):      # tuning experiments only; defaults live in render.hip
+        if os.environ.get(var):
+            extra.append(f"-D{var}=" + os.environ[var])
     objs = []
     for src in LIB_SOURCES:
         obj = os.path.join(OUT, os.path.splitext(src)[0] + ".o")
         objs.append(obj)
         if force or _stale(obj, deps):
-            cmd = [hipcc] + COMMON + ["-x", "hip", "-c", os.path.join(CSRC, src), "-o", obj]
+            cmd = [hipcc] + COMMON + extra + ["-x", "hip", "-c", os.path.join(CSRC, src), "-o", obj]
             if verbose:
                 print(" ".join(cmd), flush=True)
             subprocess.check_call(cmd)

@@ -36,6 +36,7 @@ int mirt_scene_create(const MirtSceneDesc* d, int device, MirtScene** out)
 {
   if (!d || !out) { set_error("mirt_scene_create: null argument"); return MIRT_ERR_ARG; }
   if (d->num_prims != d->num_spheres + d->num_triangles) { set_error("mirt_scene_create: num_prims != num_spheres + num_triangles"); return MIRT_ERR_ARG; }
+  if (d->num_suns + d->num_bulbs > 64) { set_error("mirt_scene_create: more than 64 lights are not supported"); return MIRT_ERR_ARG; }
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
     set_error("mirt_scene_create: no HIP device available (libmirt has no CPU path)");
@@ -126,7 +127,7 @@ void mirt_scene_destroy(MirtScene* sc)
   hipFree(sc->spheres); hipFree(sc->tris); hipFree(sc->tri_verts); hipFree(sc->mats); hipFree(sc->refs_in);
   hipFree(sc->planes); hipFree(sc->suns); hipFree(sc->bulbs);
   hipFree(sc->codes); hipFree(sc->order); hipFree(sc->child_l); hipFree(sc->child_r); hipFree(sc->parent); hipFree(sc->boxes); hipFree(sc->nodes);
-  hipFree(sc->bounds_keys); hipFree(sc->samples); hipFree(sc->stack_spill); hipFree(sc->pending); hipFree(sc->counters);
+  hipFree(sc->bounds_keys); hipFree(sc->samples); hipFree(sc->stack_spill); hipFree(sc->pending); hipFree(sc->counters); hipFree(sc->prof);
   rng_cache_free(&sc->rng);
   if (sc->ev0) hipEventDestroy(sc->ev0);
   if (sc->ev1) hipEventDestroy(sc->ev1);

@@ -18,20 +18,27 @@
 #include <climits>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 
 namespace mirt {
 namespace {
 
 constexpr int RBLOCK = 256;
-constexpr int STACK_LDS = 32;
+#ifndef MIRT_WAVES_PER_SIMD
+#define MIRT_WAVES_PER_SIMD 4   // 128 VGPRs: measured best (2: 86 ms, 3: 76 ms, 4: 68 ms, 5: 79 ms on tenthousand 1080p16)
+#endif
+#ifndef MIRT_STACK_LDS
+#define MIRT_STACK_LDS 32
+#endif
+constexpr int STACK_LDS = MIRT_STACK_LDS;
 constexpr int STACK_TOTAL = 64;      // TRAVERSAL_STACK_SIZE, bvh_traversal.cu:8
 constexpr int PENDING_WORDS = 16;
 
 constexpr float EPSILON = 0.001f;    // draw.cu:7, struct.cu:8
 
-enum : int { ST_PRIMARY = 0, ST_SHADOW, ST_REFLECT, ST_REFR_INSIDE, ST_REFR_FINAL, ST_GI };
-enum : int { M_ENTER = 0, M_LIGHT, M_REFLECT, M_POP, M_TRACE, M_DONE };
+enum : int { ST_PRIMARY = 0, ST_BATCH, ST_REFR_INSIDE, ST_REFR_FINAL, ST_GI };
+enum : int { M_BATCH = 0, M_POP, M_TRACE, M_DONE };
 enum : uint32_t { PEND_F = 1u, PEND_G = 2u };
 
 struct Mat { f3 color, shininess, trans; float ior, roughness; };
@@ -119,401 +126,532 @@ MIRT_DEV f3 rough_normal(const f3& n, float roughness, Xorwow& rng)
 
 struct Counters { uint32_t samples, rays, shadow_rays, internal_visits, sphere_tests, tri_tests, mat_fetches, max_stack; };
 
+// Everything a lane carries from one loop iteration to the next.
+struct Lane {
+  // sample being evaluated (g < 0: none)
+  long long g;
+  Xorwow rng;
+  f3 L;
+  float alpha;
+  // current shading node H: the ray that produced it and the hit
+  f3 Hdir, Hp, Hn, Hcolor;
+  int Hbounce;
+  float Hior, Hrough;
+  bool HtransNZ;
+  f3 wt, wD, pn;
+  int pc, refr_bounce, gi_n, state;
+  // the node's ray batch: shadow rays to every light, then the reflection ray; all leave from bo
+  f3 bo, rdir;
+  int li;                      // index of the batch ray in flight: < nlights shadow, == nlights reflection
+  unsigned long long occl;     // bit i: light i is occluded
+  bool batch_pending, has_reflect;
+  // ray in flight
+  f3 o, d, inv;
+  int bounce;
+  float limit;        // shadow rays: occluded iff something is hit closer than this
+  bool shadow;
+  float tplane;
+  int plane_id;
+  // traversal
+  bool trav;
+  uint32_t cur;
+  uint32_t tos;       // top of the traversal stack (entries below it live in LDS / the spill area)
+  int sp;
+  float tbest;
+  uint32_t refbest;
+};
+
+// hitNearest's plane half (checkPlane, draw.cu:581-615) and the decision whether the BVH must be walked at all.
 template <bool COUNT>
-__global__ void __launch_bounds__(RBLOCK) trace_kernel(const RenderArgs a)
+MIRT_DEV void start_ray(const RenderArgs& a, Lane& S, Counters& cn)
 {
-  __shared__ uint32_t lds_stack[STACK_LDS * RBLOCK];
-  const int tid = threadIdx.x;
-  const long long gid = (long long)blockIdx.x * RBLOCK + tid;
-  const long long gthreads = (long long)gridDim.x * RBLOCK;
+  const bool shadow = S.shadow;
+  if (COUNT) { cn.rays++; if (shadow) cn.shadow_rays++; }
+  S.inv = mk3(1.0f / S.d.x, 1.0f / S.d.y, 1.0f / S.d.z);
+  float tplane = INFINITY;
+  int plane_id = -1;
+  for (int i = 0; i < a.num_planes; ++i) {
+    const PlaneDev& pl = a.planes[i];
+    const f3 pnor = mk3(pl.nx, pl.ny, pl.nz);
+    const float t = dot(mk3(pl.px, pl.py, pl.pz) - S.o, pnor) / dot(S.d, pnor);
+    if (t <= 1e-6f) continue;
+    if (t < tplane && t > EPSILON) { tplane = t; plane_id = i; }
+  }
+  if (tplane >= (float)(INT_MAX - 10)) { tplane = INFINITY; plane_id = -1; }
+  S.tplane = tplane; S.plane_id = plane_id;
+  S.tbest = INFINITY; S.refbest = REF_NONE;
+  S.cur = a.root_ref; S.sp = 0;
+  // a shadow ray the plane already blocks needs no traversal (same boolean as draw.cu:347-352 / 365-370)
+  S.trav = (a.root_ref != REF_NONE) && !(shadow && plane_id >= 0 && tplane < S.limit);
+}
+
+MIRT_DEV void set_ray(Lane& S, const RayS& r) { S.o = r.o; S.d = r.d; S.bounce = r.bounce; }
+
+// The ray of the batch that was in flight has finished: note a shadow result, start the next ray of the batch
+// (shadow rays of diffuseLight, draw.cu:342-374, then the reflection ray of reflectionLight, draw.cu:402-404).
+// Shadow rays consume no random numbers, so tracing them after the reflection direction was drawn changes nothing.
+template <bool COUNT>
+MIRT_DEV void batch_next(const RenderArgs& a, Lane& S, Counters& cn)
+{
+  const int nlights = a.num_suns + a.num_bulbs;
+  if (S.li >= 0 && S.li < nlights) {
+    const bool occluded = (S.plane_id >= 0 && S.tplane < S.limit) || (S.refbest != REF_NONE && S.tbest < S.limit);
+    if (occluded) S.occl |= 1ull << S.li;
+  }
+  ++S.li;
+  if (S.li < nlights) {
+    // shadow ray, draw.cu:346 / 362-363
+    if (S.li < a.num_suns) {
+      const LightDev& lt = a.suns[S.li];
+      set_ray(S, mkray(S.bo, mk3(lt.x, lt.y, lt.z), 1));
+      S.limit = INFINITY;
+    } else {
+      const LightDev& lt = a.bulbs[S.li - a.num_suns];
+      const f3 bd = mk3(lt.x, lt.y, lt.z) - S.Hp;
+      set_ray(S, mkray(S.bo, bd, 1));
+      S.limit = length(bd);
+    }
+    S.shadow = true;
+    start_ray<COUNT>(a, S, cn);
+  } else if (S.li == nlights && S.has_reflect) {
+    S.o = S.bo; S.d = S.rdir; S.bounce = S.Hbounce - 1;
+    S.shadow = false;
+    S.limit = INFINITY;
+    start_ray<COUNT>(a, S, cn);
+  } else {
+    S.batch_pending = false;
+    S.shadow = false;
+    S.trav = false;
+  }
+}
+
+// Consume the finished trace of lane S and run its shading state machine until it either has the next ray
+// (S.trav / result pending again) or the sample is complete (S.g = -1 after the RGBA is written).
+template <bool COUNT>
+MIRT_DEV void advance(const RenderArgs& a, Lane& S, Counters& cn, const long long gid, const long long gthreads)
+{
+  const int nlights = a.num_suns + a.num_bulbs;
+  int micro = M_TRACE;
+  const bool bvh_hit = S.refbest != REF_NONE;
+  const bool pl_hit = S.plane_id >= 0;
+  const f3 rd0 = S.d, ro0 = S.o;
+  bool no_ray = false;     // the node had no reflection ray: nothing was traced, treat as a miss
+  if (S.state == ST_BATCH) {
+    // diffuseLight's light loops (draw.cu:342-374) with the occlusion bits the batch collected
+    f3 Dacc = mk3(0.0f, 0.0f, 0.0f);
+    for (int li = 0; li < nlights; ++li) {
+      if ((S.occl >> li) & 1ull) continue;
+      if (li < a.num_suns) {
+        const LightDev& lt = a.suns[li];
+        const float lambert = fmaxf(dot(S.pn, normalize(mk3(lt.x, lt.y, lt.z))), 0.0f);
+        const float r = S.Hcolor.x * (lt.r * lambert), gg = S.Hcolor.y * (lt.g * lambert), b = S.Hcolor.z * (lt.b * lambert);
+        Dacc = Dacc + mk3(set_expose(r, a.expose), set_expose(gg, a.expose), set_expose(b, a.expose));
+      } else {
+        const LightDev& lt = a.bulbs[li - a.num_suns];
+        const f3 bd = mk3(lt.x, lt.y, lt.z) - S.Hp;
+        const float lambert = fmaxf(dot(S.pn, normalize(bd)), 0.0f);
+        const float tl = length(bd);
+        const float inv2 = 1.0f / (tl * tl);
+        const float r = S.Hcolor.x * (lt.r * lambert), gg = S.Hcolor.y * (lt.g * lambert), b = S.Hcolor.z * (lt.b * lambert);
+        Dacc = Dacc + mk3(set_expose(r, a.expose) * inv2, set_expose(gg, a.expose) * inv2, set_expose(b, a.expose) * inv2);
+      }
+    }
+    S.L = S.L + S.wD * Dacc;
+    no_ray = !S.has_reflect;
+  }
+  {
+    // hitNearest, draw.cu:292-318: the nearer of BVH hit and plane hit (the plane wins an exact tie)
+    const bool use_bvh = !no_ray && bvh_hit && (!pl_hit || S.tbest < S.tplane);
+    const bool hit = !no_ray && (bvh_hit || pl_hit);
+    f3 Np = mk3(0, 0, 0), Nn = mk3(0, 0, 0);
+    Mat nm;
+    nm.color = mk3(0, 0, 0); nm.shininess = mk3(0, 0, 0); nm.trans = mk3(0, 0, 0); nm.ior = 1.458f; nm.roughness = 0.0f;
+    if (use_bvh) {
+      const uint32_t id = S.refbest & REF_IDMASK;
+      Np = S.tbest * rd0 + ro0;
+      if (S.refbest & REF_TRI) {
+        const float4 q0 = a.tris[3 * (size_t)id + 0], q1 = a.tris[3 * (size_t)id + 1];
+        const f3 nor = mk3(q0.w, q1.x, q1.y);
+        const float denom = dot(rd0, nor);
+        Nn = (denom < 0.0f) ? nor : -nor;
+        nm = load_mat(a.mats, (uint32_t)a.num_spheres + id);
+      } else {
+        const float4 s = a.spheres[id];
+        const f3 c = mk3(s.x, s.y, s.z);
+        const f3 cr0 = c - ro0;
+        const bool inside = (dot(cr0, cr0) < s.w * s.w);
+        Nn = normalize(inside ? (c - Np) : (Np - c));
+        nm = load_mat(a.mats, id);
+      }
+      if (COUNT) cn.mat_fetches++;
+    } else if (hit) {
+      const PlaneDev& pl = a.planes[S.plane_id];
+      const f3 pnor = mk3(pl.nx, pl.ny, pl.nz);
+      Np = S.tplane * rd0 + ro0;
+      Nn = (dot(pnor, rd0) < 0.0f) ? pnor : -pnor;
+      nm = plane_mat(pl);
+    }
+
+    if (S.state == ST_REFR_INSIDE) {
+      // second half of refractionLight, draw.cu:484-493.  No miss check: a miss yields the default ObjectInfo
+      // (normal 0, ior 1.458, point 0), which is what Np/Nn/nm hold then.
+      const f3 normal = normalize(Nn);
+      const float ior = nm.ior;
+      const float dn = dot(normal, rd0);
+      const float k = 1.0f - ior * ior * (1.0f - (dn * dn));
+      const f3 rd = ior * rd0 - (ior * (dot(normal, rd0)) + sqrtf(k)) * normal;
+      set_ray(S, mkray(Np - normal * 0.0001f, rd, S.refr_bounce - 1));
+      S.state = ST_REFR_FINAL;
+      micro = (S.bounce == 0) ? M_POP : M_TRACE;
+    } else if (!hit) {
+      // primary miss: RGBA(0,0,0,0) (draw.cu:267,284).  A secondary miss contributes nothing to rgb.
+      micro = (S.state == ST_PRIMARY) ? M_DONE : M_POP;
+    } else {
+      // refraction arguments X of the node being entered: the parent's H after a reflection (draw.cu:424), else H itself
+      f3 Xdir, Xp, Xn;
+      int Xbounce;
+      float Xior;
+      bool XtransNZ, x_parent = false, has_gi = false;
+      if (S.state == ST_PRIMARY) { S.alpha = 1.0f; S.wt = mk3(1.0f, 1.0f, 1.0f); has_gi = true; S.gi_n = a.gi; }
+      else if (S.state == ST_BATCH) x_parent = true;
+      else if (S.state == ST_GI) has_gi = true;     // gi_n was set when the ray was made
+      Xdir = S.Hdir; Xbounce = S.Hbounce; Xp = S.Hp; Xn = S.Hn; Xior = S.Hior; XtransNZ = S.HtransNZ;
+      S.Hdir = rd0; S.Hbounce = S.bounce; S.Hp = Np; S.Hn = Nn;
+      S.Hcolor = nm.color; S.Hior = nm.ior; S.Hrough = nm.roughness; S.HtransNZ = !is_black(nm.trans);
+      if (!x_parent) { Xdir = S.Hdir; Xbounce = S.Hbounce; Xp = S.Hp; Xn = S.Hn; Xior = S.Hior; XtransNZ = S.HtransNZ; }
+      // weights of this node's terms (draw.cu:277-281, 426-428, 517-519, 561-563)
+      const f3 one = mk3(1.0f, 1.0f, 1.0f);
+      const f3 Sh = nm.shininess, T = nm.trans;
+      const f3 K = (one - Sh) * (one - T);
+      if (has_gi && a.gi != 0 && S.gi_n != 0 && S.pc < a.pending_slots) {
+        const f3 w = (S.wt * K) * nm.color;
+        float* e = a.pending + ((size_t)S.pc * PENDING_WORDS) * gthreads + gid;
+        e[0 * gthreads] = __uint_as_float(PEND_G);
+        e[1 * gthreads] = S.Hp.x; e[2 * gthreads] = S.Hp.y; e[3 * gthreads] = S.Hp.z;
+        e[4 * gthreads] = S.Hn.x; e[5 * gthreads] = S.Hn.y; e[6 * gthreads] = S.Hn.z;
+        e[7 * gthreads] = __int_as_float(S.gi_n);
+        e[8 * gthreads] = w.x; e[9 * gthreads] = w.y; e[10 * gthreads] = w.z;
+        ++S.pc;
+      }
+      if (XtransNZ && Xbounce > 0 && S.pc < a.pending_slots) {
+        const f3 w = S.wt * ((one - Sh) * T);
+        float* e = a.pending + ((size_t)S.pc * PENDING_WORDS) * gthreads + gid;
+        e[0 * gthreads] = __uint_as_float(PEND_F);
+        e[1 * gthreads] = Xp.x; e[2 * gthreads] = Xp.y; e[3 * gthreads] = Xp.z;
+        e[4 * gthreads] = Xn.x; e[5 * gthreads] = Xn.y; e[6 * gthreads] = Xn.z;
+        e[7 * gthreads] = __int_as_float(Xbounce);
+        e[8 * gthreads] = w.x; e[9 * gthreads] = w.y; e[10 * gthreads] = w.z;
+        e[11 * gthreads] = Xdir.x; e[12 * gthreads] = Xdir.y; e[13 * gthreads] = Xdir.z;
+        e[14 * gthreads] = Xior;
+        ++S.pc;
+      }
+      S.wD = S.wt * K;
+      S.wt = S.wt * Sh;
+      const bool reflect_ok = !is_black(Sh) && S.Hbounce > 0;
+      // diffuseLight prologue, draw.cu:331-340
+      S.pn = S.Hn;
+      if (S.Hrough > 0.0f) S.pn = rough_normal(S.Hn, S.Hrough, S.rng);
+      S.pn = normalize(S.pn);
+      // reflectionLight prologue, draw.cu:389-402 (its draws follow diffuseLight's; the shadow rays in between draw nothing)
+      S.has_reflect = false;
+      if (reflect_ok) {
+        f3 normal = S.Hn;
+        if (S.Hrough > 0.0f) normal = rough_normal(S.Hn, S.Hrough, S.rng);
+        normal = normalize(normal);
+        S.rdir = normalize(S.Hdir - 2.0f * (dot(normal, S.Hdir)) * normal);
+        S.has_reflect = (S.Hbounce - 1) != 0;      // a bounce-0 ray never hits (draw.cu:294)
+      }
+      S.bo = S.Hp + S.Hn * EPSILON;
+      S.occl = 0ull;
+      S.li = -1;
+      S.batch_pending = true;
+      S.state = ST_BATCH;
+      micro = M_BATCH;
+    }
+  }
+
+  // run the micro-states until this lane has a ray or is finished
+  while (micro == M_POP) {
+    {
+      if (S.pc == 0) micro = M_DONE;
+      else {
+        --S.pc;
+        const float* e = a.pending + ((size_t)S.pc * PENDING_WORDS) * gthreads + gid;
+        const uint32_t tag = __float_as_uint(e[0 * gthreads]);
+        const f3 p = mk3(e[1 * gthreads], e[2 * gthreads], e[3 * gthreads]);
+        const f3 n = mk3(e[4 * gthreads], e[5 * gthreads], e[6 * gthreads]);
+        const int ib = __float_as_int(e[7 * gthreads]);
+        S.wt = mk3(e[8 * gthreads], e[9 * gthreads], e[10 * gthreads]);
+        if (tag == PEND_G) {
+          // globalIllumination, draw.cu:540-549
+          const f3 gi_dir = normalize(n + sphere_point(S.rng));
+          set_ray(S, mkray(p + n * EPSILON, gi_dir, ib - 1));
+          S.gi_n = ib - 1;
+          S.state = ST_GI;
+          micro = (S.bounce == 0) ? M_POP : M_TRACE;
+        } else {
+          // refractionLight, draw.cu:456-480
+          const f3 dir = mk3(e[11 * gthreads], e[12 * gthreads], e[13 * gthreads]);
+          const float ior = 1.0f / e[14 * gthreads];
+          const f3 normal = normalize(n);
+          const float dn = dot(normal, dir);
+          const float k = 1.0f - (ior * ior) * (1.0f - (dn * dn));
+          if (k < 0) {
+            const f3 rd = dir - 2.0f * (dot(normal, dir)) * normal;
+            set_ray(S, mkray(p + normal * EPSILON, rd, ib - 1));
+            S.state = ST_REFR_FINAL;
+            micro = (S.bounce == 0) ? M_POP : M_TRACE;
+          } else {
+            const f3 rd = ior * dir - (ior * (dot(normal, dir)) + sqrtf(k)) * normal;
+            set_ray(S, mkray(p - normal * 0.0001f, rd, ib));
+            S.refr_bounce = ib;
+            S.state = ST_REFR_INSIDE;
+            micro = M_TRACE;   // ib > 0 is guaranteed by the push condition
+          }
+        }
+      }
+    }
+  }
+  if (micro == M_DONE) {
+    a.samples[S.g] = make_float4(S.L.x, S.L.y, S.L.z, S.alpha);
+    S.g = -1;
+    S.trav = false;
+  } else if (micro == M_BATCH) {
+    batch_next<COUNT>(a, S, cn);
+  } else {
+    S.shadow = false;
+    S.limit = INFINITY;
+    start_ray<COUNT>(a, S, cn);
+  }
+}
+
+// Start sample `idx` on this lane: pixel, RNG stream, jitter, primary ray (draw.cu:105-123 / 162-171).
+template <bool COUNT>
+MIRT_DEV void init_sample(const RenderArgs& a, Lane& S, Counters& cn, const long long idx)
+{
   const int sppe = a.spp > 1 ? a.spp : 1;
   const long long stripe_pixels = (long long)a.stripe_rows * a.width;
-  const int nlights = a.num_suns + a.num_bulbs;
+  const long long lp = idx / sppe;
+  const int sidx = (int)(idx - lp * sppe);
+  const long long ls = lp / stripe_pixels;
+  const long long within = lp - ls * stripe_pixels;
+  const long long gs = ls * a.num_parts + a.part;
+  const int py = (int)(gs * a.stripe_rows + within / a.width);
+  const int px = (int)(within % a.width);
+  const uint32_t pixel = (uint32_t)py * (uint32_t)a.width + (uint32_t)px;
+  S.g = idx;
+  S.L = mk3(0.0f, 0.0f, 0.0f);
+  S.alpha = 0.0f;
+  S.pc = 0;
+  S.state = ST_PRIMARY;
+  S.limit = INFINITY;
+  S.shadow = false;
+  S.batch_pending = false;
+  if (a.needs_rng) xw_init(S.rng, a.rng, pixel, (uint32_t)sidx);
+  float fx = (float)px, fy = (float)py;
+  if (a.spp >= 1) {
+    const float jx = randD(-0.5f, 0.5f, S.rng);
+    const float jy = randD(-0.5f, 0.5f, S.rng);
+    fx = (float)px + jx; fy = (float)py + jy;
+  }
+  set_ray(S, primary_ray(a, fx, fy, S.rng));
+  if (COUNT) cn.samples++;
+  if (S.bounce == 0) {   // hitNearest: a ray with bounce 0 never hits (draw.cu:294)
+    a.samples[idx] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    S.g = -1;
+    S.trav = false;
+  } else {
+    start_ray<COUNT>(a, S, cn);
+  }
+}
+
+template <bool COUNT, bool PROF>
+__global__ void __launch_bounds__(RBLOCK, MIRT_WAVES_PER_SIMD) trace_kernel(const RenderArgs a)
+{
+  // PROF: diagnostic build only -- cycle stamps per phase, written to a.prof (never used for timing claims)
+  unsigned long long pf_S = 0, pf_T = 0, pf_iters = 0, pf_active = 0, pf_Sent = 0, pf_Slanes = 0, pf_Bent = 0, pf_Blanes = 0, pf_leaf = 0, pf_node = 0;
+  const unsigned long long pf_t0 = PROF ? clock64() : 0;
+  __shared__ uint32_t lds_stack[STACK_LDS * RBLOCK];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const long long gid = (long long)blockIdx.x * RBLOCK + tid;
+  const long long gthreads = (long long)gridDim.x * RBLOCK;
   Counters cn = {0, 0, 0, 0, 0, 0, 0, 0};
 
-  // every wave walks the sample range in steps of the grid size; lanes of a wave hold consecutive samples
-  const long long wave_first = gid - (tid & 63);
-  for (long long g0 = wave_first; g0 < a.num_samples; g0 += gthreads) {
-    const long long g = g0 + (tid & 63);
-    bool alive = g < a.num_samples;
+  // Work distribution without atomics: the sample range is cut into blocks of 64 consecutive samples (4 pixels at
+  // 16 spp); wave w owns blocks w, w + nwaves, w + 2 nwaves, ... and its lanes draw samples from them in order.
+  const long long nwaves = gthreads / 64;
+  const long long wave_id = gid / 64;
+  const long long nblocks64 = (a.num_samples + 63) / 64;
+  const long long my_blocks = (nblocks64 > wave_id) ? (nblocks64 - 1 - wave_id) / nwaves + 1 : 0;
+  const long long my_total = my_blocks * 64;
+  long long consumed = 0;       // wave-uniform
 
-    // ---- sample -> pixel ------------------------------------------------------------------------
-    int px = 0, py = 0, sidx = 0;
-    uint32_t pixel = 0;
-    if (alive) {
-      const long long lp = g / sppe;
-      sidx = (int)(g - lp * sppe);
-      const long long ls = lp / stripe_pixels;
-      const long long within = lp - ls * stripe_pixels;
-      const long long gs = ls * a.num_parts + a.part;
-      py = (int)(gs * a.stripe_rows + within / a.width);
-      px = (int)(within % a.width);
-      pixel = (uint32_t)py * (uint32_t)a.width + (uint32_t)px;
+  Lane S;
+  S.g = -1; S.trav = false;
+  S.rng.v0 = S.rng.v1 = S.rng.v2 = S.rng.v3 = S.rng.v4 = S.rng.d = 0; S.rng.bm_flag = 0; S.rng.bm_extra = 0.0f;
+  S.L = mk3(0, 0, 0); S.alpha = 0.0f;
+  S.Hdir = mk3(0, 0, 0); S.Hp = mk3(0, 0, 0); S.Hn = mk3(0, 0, 0); S.Hcolor = mk3(0, 0, 0);
+  S.Hbounce = 0; S.Hior = 1.458f; S.Hrough = 0.0f; S.HtransNZ = false;
+  S.wt = mk3(1, 1, 1); S.wD = mk3(0, 0, 0); S.pn = mk3(0, 0, 0);
+  S.pc = 0; S.refr_bounce = 0; S.gi_n = 0; S.state = ST_PRIMARY;
+  S.bo = mk3(0, 0, 0); S.rdir = mk3(0, 0, 1); S.li = 0; S.occl = 0ull; S.batch_pending = false; S.has_reflect = false;
+  S.o = mk3(0, 0, 0); S.d = mk3(0, 0, 1); S.inv = mk3(0, 0, 1); S.bounce = 0; S.limit = INFINITY; S.shadow = false;
+  S.tplane = INFINITY; S.plane_id = -1;
+  S.cur = REF_NONE; S.tos = REF_NONE; S.sp = 0; S.tbest = INFINITY; S.refbest = REF_NONE;
+
+  for (;;) {
+    // ================= shade / refill phase: lanes that are not traversing =================
+    unsigned long long pf_a = 0;
+    if (PROF) { pf_a = clock64(); pf_Sent++; pf_Slanes += __popcll(__ballot(!S.trav && S.g >= 0)); }
+    while (!S.trav && S.g >= 0) {
+      if (S.batch_pending) batch_next<COUNT>(a, S, cn);
+      else advance<COUNT>(a, S, cn, gid, gthreads);
     }
-
-    // ---- per-sample state -------------------------------------------------------------------------
-    Xorwow rng;
-    rng.v0 = rng.v1 = rng.v2 = rng.v3 = rng.v4 = rng.d = 0; rng.bm_flag = 0; rng.bm_extra = 0.0f;
-    f3 L = mk3(0.0f, 0.0f, 0.0f);
-    float alpha = 0.0f;
-    // current shading node H (ray that produced it + hit)
-    f3 Hdir = mk3(0, 0, 0), Hp = mk3(0, 0, 0), Hn = mk3(0, 0, 0), Hcolor = mk3(0, 0, 0);
-    int Hbounce = 0;
-    float Hior = 1.458f, Hrough = 0.0f;
-    bool HtransNZ = false, reflect_ok = false;
-    // refraction arguments X of the node being entered (the parent's H after a reflection, else H itself)
-    f3 Xdir = mk3(0, 0, 0), Xp = mk3(0, 0, 0), Xn = mk3(0, 0, 0);
-    int Xbounce = 0;
-    float Xior = 1.458f;
-    bool XtransNZ = false, x_parent = false;
-    bool has_gi = false;
-    int gi_n = 0;
-    f3 wt = mk3(1.0f, 1.0f, 1.0f), wD = mk3(0, 0, 0), Dacc = mk3(0, 0, 0), pn = mk3(0, 0, 0);
-    int li = 0, pc = 0, refr_bounce = 0;
-    // the ray to trace next
-    RayS ray; ray.o = mk3(0, 0, 0); ray.d = mk3(0, 0, 1); ray.bounce = 0;
-    float limit = INFINITY;     // shadow rays: occluded iff something is hit closer than this
-    int state = ST_PRIMARY;
-    bool want = false;          // this lane has a ray for the trace phase
-
-    if (alive) {
-      if (a.needs_rng) xw_init(rng, a.rng, pixel, (uint32_t)sidx);
-      float fx = (float)px, fy = (float)py;
-      if (a.spp >= 1) {   // draw.cu:120-121 / 165-168
-        const float jx = randD(-0.5f, 0.5f, rng);
-        const float jy = randD(-0.5f, 0.5f, rng);
-        fx = (float)px + jx; fy = (float)py + jy;
-      }
-      ray = primary_ray(a, fx, fy, rng);
-      if (COUNT) cn.samples++;
-      if (ray.bounce == 0) alive = false;   // hitNearest: bounce 0 never hits (draw.cu:294)
-      else want = true;
-    }
-
-    while (__ballot(alive)) {
-      // =========================== trace phase (all lanes together) ===========================
-      float tbest = INFINITY;
-      uint32_t refbest = REF_NONE;     // leaf reference of the best BVH hit
-      float tplane = INFINITY;
-      int plane_id = -1;
-      const bool shadow = (state == ST_SHADOW);
-      bool trav = false;
-      if (want) {
-        if (COUNT) { cn.rays++; if (shadow) cn.shadow_rays++; }
-        // checkPlane, draw.cu:581-615
-        for (int i = 0; i < a.num_planes; ++i) {
-          const PlaneDev& pl = a.planes[i];
-          const f3 pnor = mk3(pl.nx, pl.ny, pl.nz);
-          const float t = dot(mk3(pl.px, pl.py, pl.pz) - ray.o, pnor) / dot(ray.d, pnor);
-          if (t <= 1e-6f) continue;
-          if (t < tplane && t > EPSILON) { tplane = t; plane_id = i; }
-        }
-        if (tplane >= (float)(INT_MAX - 10)) { tplane = INFINITY; plane_id = -1; }
-        trav = (a.root_ref != REF_NONE) && !(shadow && plane_id >= 0 && tplane < limit);
-      }
-      {
-        // traverse_lbvh, bvh_traversal.cu:92-183
-        const f3 inv = mk3(1.0f / ray.d.x, 1.0f / ray.d.y, 1.0f / ray.d.z);
-        const float tmin = 0.0001f;
-        uint32_t cur = a.root_ref;
-        int sp = 0;
-        while (__ballot(trav)) {
-          if (trav) {
-            if (cur & REF_LEAF) {
-              // intersect_leaf_primitives, bvh_traversal.cu:47-89
-              const uint32_t id = cur & REF_IDMASK;
-              float t = 0.0f;
-              bool hit = false;
-              if (cur & REF_TRI) {
-                // checkTriangleIntersectionSoA, struct.cu:111-163
-                const float4 q0 = a.tris[3 * (size_t)id + 0], q1 = a.tris[3 * (size_t)id + 1], q2 = a.tris[3 * (size_t)id + 2];
-                if (COUNT) cn.tri_tests++;
-                const f3 p0 = mk3(q0.x, q0.y, q0.z), nor = mk3(q0.w, q1.x, q1.y);
-                const float denom = dot(ray.d, nor);
-                if (!(fabsf(denom) < 1e-9f)) {
-                  t = dot(p0 - ray.o, nor) / denom;
-                  if (!(t <= EPSILON)) {
-                    const f3 ip = t * ray.d + ray.o;
-                    const f3 e1 = mk3(q1.z, q1.w, q2.x), e2 = mk3(q2.y, q2.z, q2.w);
-                    const float b1 = dot(e1, ip - p0);
-                    const float b2 = dot(e2, ip - p0);
-                    const float b0 = 1.0f - b1 - b2;
-                    hit = (b0 >= -EPSILON) && (b1 >= -EPSILON) && (b2 >= -EPSILON);
-                  }
-                }
-              } else {
-                // checkSphereIntersectionSoA, struct.cu:64-109
-                const float4 s = a.spheres[id];
-                if (COUNT) cn.sphere_tests++;
-                const f3 c = mk3(s.x, s.y, s.z);
-                const float r = s.w;
-                const f3 cr0 = c - ray.o;
-                const bool inside = (dot(cr0, cr0) < r * r);
-                const float tc = dot(cr0, ray.d);
-                if (!(!inside && tc < 0.0f)) {
-                  const f3 dv = ray.o + (tc * ray.d) - c;
-                  const float d2 = dot(dv, dv);
-                  if (!(!inside && (r * r) < d2)) {
-                    const float toff = sqrtf((r * r) - d2);
-                    t = inside ? (tc + toff) : (tc - toff);
-                    hit = true;
-                  }
-                }
-              }
-              if (hit && t > 1e-6f && t < tbest) {
-                tbest = t; refbest = cur;
-                if (shadow && tbest < limit) trav = false;      // any-hit exit: the caller only asks "closer than limit?"
-              }
-              if (trav) {
-                if (sp == 0) trav = false;
-                else {
-                  --sp;
-                  cur = (sp < STACK_LDS) ? lds_stack[sp * RBLOCK + tid] : a.stack_spill[(size_t)(sp - STACK_LDS) * gthreads + gid];
-                }
-              }
-            } else {
-              const float4 n0 = a.nodes[4 * (size_t)cur + 0], n1 = a.nodes[4 * (size_t)cur + 1];
-              const float4 n2 = a.nodes[4 * (size_t)cur + 2], n3 = a.nodes[4 * (size_t)cur + 3];
-              if (COUNT) cn.internal_visits++;
-              // hit_aabb_adapted, bvh_traversal.cu:11-44, on both children
-              float tx1 = (n0.x - ray.o.x) * inv.x, tx2 = (n0.w - ray.o.x) * inv.x;
-              float ty1 = (n0.y - ray.o.y) * inv.y, ty2 = (n1.x - ray.o.y) * inv.y;
-              float tz1 = (n0.z - ray.o.z) * inv.z, tz2 = (n1.y - ray.o.z) * inv.z;
-              float te = fmaxf(fmaxf(fminf(tx1, tx2), fminf(ty1, ty2)), fminf(tz1, tz2));
-              float tx = fminf(fminf(fmaxf(tx1, tx2), fmaxf(ty1, ty2)), fmaxf(tz1, tz2));
-              const bool hl = te < tx && te < tbest && tx > tmin;
-              tx1 = (n1.z - ray.o.x) * inv.x; tx2 = (n2.y - ray.o.x) * inv.x;
-              ty1 = (n1.w - ray.o.y) * inv.y; ty2 = (n2.z - ray.o.y) * inv.y;
-              tz1 = (n2.x - ray.o.z) * inv.z; tz2 = (n2.w - ray.o.z) * inv.z;
-              te = fmaxf(fmaxf(fminf(tx1, tx2), fminf(ty1, ty2)), fminf(tz1, tz2));
-              tx = fminf(fminf(fmaxf(tx1, tx2), fmaxf(ty1, ty2)), fmaxf(tz1, tz2));
-              const bool hr = te < tx && te < tbest && tx > tmin;
-              const uint32_t lref = __float_as_uint(n3.x), rref = __float_as_uint(n3.y);
-              if (hl && hr) {
-                cur = lref;
-                if (sp < STACK_TOTAL) {
-                  if (sp < STACK_LDS) lds_stack[sp * RBLOCK + tid] = rref;
-                  else a.stack_spill[(size_t)(sp - STACK_LDS) * gthreads + gid] = rref;
-                  ++sp;
-                  if (COUNT) cn.max_stack = max(cn.max_stack, (uint32_t)sp);
-                }
-              } else if (hl) cur = lref;
-              else if (hr) cur = rref;
-              else {
-                if (sp == 0) trav = false;
-                else {
-                  --sp;
-                  cur = (sp < STACK_LDS) ? lds_stack[sp * RBLOCK + tid] : a.stack_spill[(size_t)(sp - STACK_LDS) * gthreads + gid];
-                }
-              }
-            }
-          }
+    if (consumed < my_total) {
+      const unsigned long long need = __ballot(!S.trav && S.g < 0);
+      if (need) {
+        const int r = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(need >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)need, 0u));
+        const long long k = consumed + r;
+        consumed += __popcll(need);
+        if (!S.trav && S.g < 0 && k < my_total) {
+          const long long idx = ((k >> 6) * nwaves + wave_id) * 64 + (k & 63);
+          if (idx < a.num_samples) init_sample<COUNT>(a, S, cn, idx);
         }
       }
+    }
+    if (__ballot(S.trav) == 0) {
+      if (consumed >= my_total && __ballot(S.g >= 0) == 0) break;
+      continue;
+    }
 
-      // =========================== shade phase (per lane) ===========================
-      if (alive) {
-        int micro = M_TRACE;
-        // ---- consume the trace result -------------------------------------------------------------
-        // hitNearest, draw.cu:292-318: the nearer of BVH hit and plane hit (the plane wins an exact tie)
-        const bool bvh_hit = refbest != REF_NONE;
-        const bool pl_hit = plane_id >= 0;
-        if (state == ST_SHADOW) {
-          const bool occluded = (pl_hit && tplane < limit) || (bvh_hit && tbest < limit);
-          if (!occluded) {
-            // draw.cu:354-355 / 372-373
-            if (li < a.num_suns) {
-              const LightDev& lt = a.suns[li];
-              const float lambert = fmaxf(dot(pn, ray.d), 0.0f);   // ray.d == normalize(light.dir)
-              const float r = Hcolor.x * (lt.r * lambert), gg = Hcolor.y * (lt.g * lambert), b = Hcolor.z * (lt.b * lambert);
-              Dacc = Dacc + mk3(set_expose(r, a.expose), set_expose(gg, a.expose), set_expose(b, a.expose));
-            } else {
-              const LightDev& lt = a.bulbs[li - a.num_suns];
-              const float lambert = fmaxf(dot(pn, ray.d), 0.0f);   // ray.d == normalize(bulbDir)
-              const float tl = limit;                               // == bulbDir.length()
-              const float inv2 = 1.0f / (tl * tl);
-              const float r = Hcolor.x * (lt.r * lambert), gg = Hcolor.y * (lt.g * lambert), b = Hcolor.z * (lt.b * lambert);
-              Dacc = Dacc + mk3(set_expose(r, a.expose) * inv2, set_expose(gg, a.expose) * inv2, set_expose(b, a.expose) * inv2);
+    // ================= traversal phase: traverse_lbvh, bvh_traversal.cu:92-183 =================
+    const float tmin = 0.0001f;
+    unsigned long long pf_b = 0;
+    if (PROF) { pf_b = clock64(); pf_S += pf_b - pf_a; }
+    for (;;) {
+      const unsigned long long tm = __ballot(S.trav);
+      const unsigned long long bm = __ballot(!S.trav && S.batch_pending);
+      if (tm == 0 && bm == 0) break;
+      // leave when enough lanes are waiting to shade (they cannot progress while the wave keeps traversing)
+      if (__popcll(__ballot(!S.trav && !S.batch_pending && S.g >= 0)) >= a.refill_k) break;
+      // lanes whose batch ray finished move on to the next ray of their batch (cheap; done in groups)
+      if (bm != 0 && (__popcll(bm) >= a.batch_k || tm == 0)) {
+        if (PROF) { pf_Bent++; pf_Blanes += __popcll(bm); }
+        if (!S.trav && S.batch_pending) batch_next<COUNT>(a, S, cn);
+      }
+      if (PROF) { pf_iters++; pf_active += __popcll(__ballot(S.trav)); pf_leaf += __popcll(__ballot(S.trav && (S.cur & REF_LEAF))); }
+      if (S.trav) {
+        // one fetch per iteration: the record `cur` names -- a node (4 x 16 B) or a primitive (sphere 16 B, triangle 48 B)
+        const bool leaf = (S.cur & REF_LEAF) != 0;
+        const bool tri = leaf && (S.cur & REF_TRI);
+        const uint32_t id = S.cur & REF_IDMASK;
+        const float4* rec = leaf ? (tri ? a.tris + 3 * (size_t)id : a.spheres + id) : a.nodes + 4 * (size_t)S.cur;
+        const float4 q0 = rec[0];
+        float4 q1 = make_float4(0, 0, 0, 0), q2 = q1, q3 = q1;
+        if (!leaf || tri) { q1 = rec[1]; q2 = rec[2]; }
+        if (!leaf) q3 = rec[3];
+        bool pop = false;
+        if (leaf) {
+          // intersect_leaf_primitives, bvh_traversal.cu:47-89
+          float t = 0.0f;
+          bool hit = false;
+          if (tri) {
+            // checkTriangleIntersectionSoA, struct.cu:111-163
+            if (COUNT) cn.tri_tests++;
+            const f3 p0 = mk3(q0.x, q0.y, q0.z), nor = mk3(q0.w, q1.x, q1.y);
+            const float denom = dot(S.d, nor);
+            if (!(fabsf(denom) < 1e-9f)) {
+              t = dot(p0 - S.o, nor) / denom;
+              if (!(t <= EPSILON)) {
+                const f3 ip = t * S.d + S.o;
+                const f3 e1 = mk3(q1.z, q1.w, q2.x), e2 = mk3(q2.y, q2.z, q2.w);
+                const float b1 = dot(e1, ip - p0);
+                const float b2 = dot(e2, ip - p0);
+                const float b0 = 1.0f - b1 - b2;
+                hit = (b0 >= -EPSILON) && (b1 >= -EPSILON) && (b2 >= -EPSILON);
+              }
             }
-          }
-          ++li;
-          micro = M_LIGHT;
-        } else {
-          const bool use_bvh = bvh_hit && (!pl_hit || tbest < tplane);
-          const bool hit = bvh_hit || pl_hit;
-          // resolve the hit: point, normal, material (same expressions as the primitive tests)
-          f3 Np = mk3(0, 0, 0), Nn = mk3(0, 0, 0);
-          Mat nm;
-          nm.color = mk3(0, 0, 0); nm.shininess = mk3(0, 0, 0); nm.trans = mk3(0, 0, 0); nm.ior = 1.458f; nm.roughness = 0.0f;
-          if (use_bvh) {
-            const uint32_t id = refbest & REF_IDMASK;
-            Np = tbest * ray.d + ray.o;
-            if (refbest & REF_TRI) {
-              const float4 q0 = a.tris[3 * (size_t)id + 0], q1 = a.tris[3 * (size_t)id + 1];
-              const f3 nor = mk3(q0.w, q1.x, q1.y);
-              const float denom = dot(ray.d, nor);
-              Nn = (denom < 0.0f) ? nor : -nor;
-              nm = load_mat(a.mats, (uint32_t)a.num_spheres + id);
-            } else {
-              const float4 s = a.spheres[id];
-              const f3 c = mk3(s.x, s.y, s.z);
-              const f3 cr0 = c - ray.o;
-              const bool inside = (dot(cr0, cr0) < s.w * s.w);
-              Nn = normalize(inside ? (c - Np) : (Np - c));
-              nm = load_mat(a.mats, id);
-            }
-            if (COUNT) cn.mat_fetches++;
-          } else if (pl_hit) {
-            const PlaneDev& pl = a.planes[plane_id];
-            const f3 pnor = mk3(pl.nx, pl.ny, pl.nz);
-            Np = tplane * ray.d + ray.o;
-            Nn = (dot(pnor, ray.d) < 0.0f) ? pnor : -pnor;
-            nm = plane_mat(pl);
-          }
-
-          if (state == ST_REFR_INSIDE) {
-            // second half of refractionLight, draw.cu:484-493.  No miss check: a miss yields the default ObjectInfo
-            // (normal 0, ior 1.458, point 0), which the code above has already produced in Np/Nn/nm.
-            const f3 normal = normalize(Nn);
-            const float ior = nm.ior;
-            const f3 dir = ray.d;
-            const float dn = dot(normal, dir);
-            const float k = 1.0f - ior * ior * (1.0f - (dn * dn));
-            const f3 rd = ior * dir - (ior * (dot(normal, dir)) + sqrtf(k)) * normal;
-            ray = mkray(Np - normal * 0.0001f, rd, refr_bounce - 1);
-            state = ST_REFR_FINAL;
-            micro = (ray.bounce == 0) ? M_POP : M_TRACE;
-          } else if (!hit) {
-            // primary miss: RGBA(0,0,0,0) (draw.cu:267,284).  Secondary miss contributes nothing to rgb.
-            micro = (state == ST_PRIMARY) ? M_DONE : M_POP;
           } else {
-            if (state == ST_PRIMARY) { alpha = 1.0f; wt = mk3(1.0f, 1.0f, 1.0f); x_parent = false; has_gi = true; gi_n = a.gi; }
-            else if (state == ST_REFLECT) {
-              // the new node's refraction term uses the ORIGINAL ray and object (draw.cu:424)
-              Xdir = Hdir; Xbounce = Hbounce; Xp = Hp; Xn = Hn; Xior = Hior; XtransNZ = HtransNZ; x_parent = true; has_gi = false;
-            } else if (state == ST_REFR_FINAL) { x_parent = false; has_gi = false; }
-            else { x_parent = false; has_gi = true; }   // ST_GI: gi_n was set when the ray was made
-            Hdir = ray.d; Hbounce = ray.bounce; Hp = Np; Hn = Nn;
-            Hcolor = nm.color; Hior = nm.ior; Hrough = nm.roughness; HtransNZ = !is_black(nm.trans);
-            // ---- M_ENTER: weights of this node's four terms (draw.cu:277-281, 426-428, 517-519, 561-563) ----
-            const f3 one = mk3(1.0f, 1.0f, 1.0f);
-            const f3 S = nm.shininess, T = nm.trans;
-            const f3 K = (one - S) * (one - T);
-            if (has_gi && a.gi != 0 && gi_n != 0 && pc < a.pending_slots) {
-              const f3 w = (wt * K) * nm.color;
-              float* e = a.pending + ((size_t)pc * PENDING_WORDS) * gthreads + gid;
-              e[0 * gthreads] = __uint_as_float(PEND_G);
-              e[1 * gthreads] = Hp.x; e[2 * gthreads] = Hp.y; e[3 * gthreads] = Hp.z;
-              e[4 * gthreads] = Hn.x; e[5 * gthreads] = Hn.y; e[6 * gthreads] = Hn.z;
-              e[7 * gthreads] = __int_as_float(gi_n);
-              e[8 * gthreads] = w.x; e[9 * gthreads] = w.y; e[10 * gthreads] = w.z;
-              ++pc;
-            }
-            if (!x_parent) { Xdir = Hdir; Xbounce = Hbounce; Xp = Hp; Xn = Hn; Xior = Hior; XtransNZ = HtransNZ; }
-            if (XtransNZ && Xbounce > 0 && pc < a.pending_slots) {
-              const f3 w = wt * ((one - S) * T);
-              float* e = a.pending + ((size_t)pc * PENDING_WORDS) * gthreads + gid;
-              e[0 * gthreads] = __uint_as_float(PEND_F);
-              e[1 * gthreads] = Xp.x; e[2 * gthreads] = Xp.y; e[3 * gthreads] = Xp.z;
-              e[4 * gthreads] = Xn.x; e[5 * gthreads] = Xn.y; e[6 * gthreads] = Xn.z;
-              e[7 * gthreads] = __int_as_float(Xbounce);
-              e[8 * gthreads] = w.x; e[9 * gthreads] = w.y; e[10 * gthreads] = w.z;
-              e[11 * gthreads] = Xdir.x; e[12 * gthreads] = Xdir.y; e[13 * gthreads] = Xdir.z;
-              e[14 * gthreads] = Xior;
-              ++pc;
-            }
-            wD = wt * K;
-            wt = wt * S;
-            reflect_ok = !is_black(S) && Hbounce > 0;
-            // diffuseLight prologue, draw.cu:331-340
-            pn = Hn;
-            if (Hrough > 0.0f) pn = rough_normal(Hn, Hrough, rng);
-            pn = normalize(pn);
-            Dacc = mk3(0.0f, 0.0f, 0.0f);
-            li = 0;
-            micro = M_LIGHT;
-          }
-        }
-
-        // ---- run the micro-states until this lane has a ray or is finished ---------------------------
-        while (micro != M_TRACE && micro != M_DONE) {
-          if (micro == M_LIGHT) {
-            if (li < nlights) {
-              // shadow ray, draw.cu:346 / 362-363
-              if (li < a.num_suns) {
-                const LightDev& lt = a.suns[li];
-                ray = mkray(Hp + Hn * EPSILON, mk3(lt.x, lt.y, lt.z), 1);
-                limit = INFINITY;
-              } else {
-                const LightDev& lt = a.bulbs[li - a.num_suns];
-                const f3 bd = mk3(lt.x, lt.y, lt.z) - Hp;
-                ray = mkray(Hp + Hn * EPSILON, bd, 1);
-                limit = length(bd);
-              }
-              state = ST_SHADOW;
-              micro = M_TRACE;
-            } else {
-              L = L + wD * Dacc;
-              micro = M_REFLECT;
-            }
-          } else if (micro == M_REFLECT) {
-            // reflectionLight, draw.cu:389-404
-            if (!reflect_ok) micro = M_POP;
-            else {
-              f3 normal = Hn;
-              if (Hrough > 0.0f) normal = rough_normal(Hn, Hrough, rng);
-              normal = normalize(normal);
-              const f3 rd = Hdir - 2.0f * (dot(normal, Hdir)) * normal;
-              ray = mkray(Hp + Hn * EPSILON, rd, Hbounce - 1);
-              state = ST_REFLECT;
-              micro = (ray.bounce == 0) ? M_POP : M_TRACE;
-            }
-          } else {   // M_POP
-            if (pc == 0) micro = M_DONE;
-            else {
-              --pc;
-              const float* e = a.pending + ((size_t)pc * PENDING_WORDS) * gthreads + gid;
-              const uint32_t tag = __float_as_uint(e[0 * gthreads]);
-              const f3 p = mk3(e[1 * gthreads], e[2 * gthreads], e[3 * gthreads]);
-              const f3 n = mk3(e[4 * gthreads], e[5 * gthreads], e[6 * gthreads]);
-              const int ib = __float_as_int(e[7 * gthreads]);
-              wt = mk3(e[8 * gthreads], e[9 * gthreads], e[10 * gthreads]);
-              if (tag == PEND_G) {
-                // globalIllumination, draw.cu:540-549
-                const f3 gi_dir = normalize(n + sphere_point(rng));
-                ray = mkray(p + n * EPSILON, gi_dir, ib - 1);
-                gi_n = ib - 1;
-                state = ST_GI;
-                micro = (ray.bounce == 0) ? M_POP : M_TRACE;
-              } else {
-                // refractionLight, draw.cu:456-480
-                const f3 dir = mk3(e[11 * gthreads], e[12 * gthreads], e[13 * gthreads]);
-                const float ior = 1.0f / e[14 * gthreads];
-                const f3 normal = normalize(n);
-                const float dn = dot(normal, dir);
-                const float k = 1.0f - (ior * ior) * (1.0f - (dn * dn));
-                if (k < 0) {
-                  const f3 rd = dir - 2.0f * (dot(normal, dir)) * normal;
-                  ray = mkray(p + normal * EPSILON, rd, ib - 1);
-                  state = ST_REFR_FINAL;
-                  micro = (ray.bounce == 0) ? M_POP : M_TRACE;
-                } else {
-                  const f3 rd = ior * dir - (ior * (dot(normal, dir)) + sqrtf(k)) * normal;
-                  ray = mkray(p - normal * 0.0001f, rd, ib);
-                  refr_bounce = ib;
-                  state = ST_REFR_INSIDE;
-                  micro = M_TRACE;   // ib > 0 is guaranteed by the push condition
-                }
+            // checkSphereIntersectionSoA, struct.cu:64-109
+            if (COUNT) cn.sphere_tests++;
+            const f3 c = mk3(q0.x, q0.y, q0.z);
+            const float r = q0.w;
+            const f3 cr0 = c - S.o;
+            const bool inside = (dot(cr0, cr0) < r * r);
+            const float tc = dot(cr0, S.d);
+            if (!(!inside && tc < 0.0f)) {
+              const f3 dv = S.o + (tc * S.d) - c;
+              const float d2 = dot(dv, dv);
+              if (!(!inside && (r * r) < d2)) {
+                const float toff = sqrtf((r * r) - d2);
+                t = inside ? (tc + toff) : (tc - toff);
+                hit = true;
               }
             }
           }
+          if (hit && t > 1e-6f && t < S.tbest) {
+            S.tbest = t; S.refbest = S.cur;
+            if (S.shadow && S.tbest < S.limit) S.trav = false;      // any-hit exit
+          }
+          pop = S.trav;
+        } else {
+          if (COUNT) cn.internal_visits++;
+          // hit_aabb_adapted, bvh_traversal.cu:11-44, on both children
+          float tx1 = (q0.x - S.o.x) * S.inv.x, tx2 = (q0.w - S.o.x) * S.inv.x;
+          float ty1 = (q0.y - S.o.y) * S.inv.y, ty2 = (q1.x - S.o.y) * S.inv.y;
+          float tz1 = (q0.z - S.o.z) * S.inv.z, tz2 = (q1.y - S.o.z) * S.inv.z;
+          float te = fmaxf(fmaxf(fminf(tx1, tx2), fminf(ty1, ty2)), fminf(tz1, tz2));
+          float tx = fminf(fminf(fmaxf(tx1, tx2), fmaxf(ty1, ty2)), fmaxf(tz1, tz2));
+          const bool hl = te < tx && te < S.tbest && tx > tmin;
+          tx1 = (q1.z - S.o.x) * S.inv.x; tx2 = (q2.y - S.o.x) * S.inv.x;
+          ty1 = (q1.w - S.o.y) * S.inv.y; ty2 = (q2.z - S.o.y) * S.inv.y;
+          tz1 = (q2.x - S.o.z) * S.inv.z; tz2 = (q2.w - S.o.z) * S.inv.z;
+          te = fmaxf(fmaxf(fminf(tx1, tx2), fminf(ty1, ty2)), fminf(tz1, tz2));
+          tx = fminf(fminf(fmaxf(tx1, tx2), fmaxf(ty1, ty2)), fmaxf(tz1, tz2));
+          const bool hr = te < tx && te < S.tbest && tx > tmin;
+          const uint32_t lref = __float_as_uint(q3.x), rref = __float_as_uint(q3.y);
+          if (hl && hr) {
+            S.cur = lref;
+            // push right: the previous top of stack goes to memory, the new top stays in a register
+            if (S.sp < STACK_TOTAL) {
+              if (S.sp > 0) {
+                const int slot = S.sp - 1;
+                if (slot < STACK_LDS) lds_stack[slot * RBLOCK + tid] = S.tos;
+                else a.stack_spill[(size_t)(slot - STACK_LDS) * gthreads + gid] = S.tos;
+              }
+              S.tos = rref;
+              ++S.sp;
+              if (COUNT) cn.max_stack = max(cn.max_stack, (uint32_t)S.sp);
+            }
+          } else if (hl) S.cur = lref;
+          else if (hr) S.cur = rref;
+          else pop = true;
         }
-        if (micro == M_DONE) alive = false;
+        if (pop) {
+          if (S.sp == 0) S.trav = false;
+          else {
+            S.cur = S.tos;
+            --S.sp;
+            if (S.sp > 0) {
+              const int slot = S.sp - 1;
+              S.tos = lds_stack[(slot < STACK_LDS ? slot : 0) * RBLOCK + tid];
+              if (slot >= STACK_LDS) S.tos = a.stack_spill[(size_t)(slot - STACK_LDS) * gthreads + gid];
+            }
+          }
+        }
       }
-      want = alive;
     }
-    if (g < a.num_samples) a.samples[g] = make_float4(L.x, L.y, L.z, alpha);
+    if (PROF) pf_T += clock64() - pf_b;
   }
+  (void)lane;
+  if (PROF && a.prof && (tid & 63) == 0) {
+    const unsigned long long tot = clock64() - pf_t0;
+    atomicAdd(&a.prof[0], tot); atomicAdd(&a.prof[1], pf_S); atomicAdd(&a.prof[2], pf_T); atomicAdd(&a.prof[3], pf_iters);
+    atomicAdd(&a.prof[4], pf_active); atomicAdd(&a.prof[5], pf_Sent); atomicAdd(&a.prof[6], pf_Slanes); atomicAdd(&a.prof[7], pf_Bent);
+    atomicAdd(&a.prof[8], pf_Blanes); atomicAdd(&a.prof[9], pf_leaf); atomicAdd(&a.prof[10], 1ull);
+  }
+  (void)pf_node;
 
   if (COUNT && a.counters) {
     uint32_t v[8] = {cn.samples, cn.rays, cn.shadow_rays, cn.internal_visits, cn.sphere_tests, cn.tri_tests, cn.mat_fetches, cn.max_stack};
@@ -682,7 +820,7 @@ static int grid_blocks(int device)
   hipDeviceProp_t prop;
   if (hipGetDeviceProperties(&prop, device) != hipSuccess) return 1024;
   int per_cu = 0;
-  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, trace_kernel<false>, RBLOCK, 0) != hipSuccess || per_cu < 1) per_cu = 4;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, trace_kernel<false, false>, RBLOCK, 0) != hipSuccess || per_cu < 1) per_cu = 4;
   return prop.multiProcessorCount * per_cu;
 }
 
@@ -753,12 +891,28 @@ int render(MirtScene* sc, const MirtRenderParams* p, void* d_rgba8, void* d_rgba
   a.stack_spill = sc->stack_spill;
   a.pending = sc->pending; a.pending_slots = pending_slots;
   a.counters = count ? sc->counters : nullptr;
+  a.refill_k = 32;
+  a.batch_k = 8;
+  if (const char* e = getenv("MIRT_BATCH_K")) { int k = atoi(e); if (k >= 1 && k <= 64) a.batch_k = k; }
+  if (const char* e = getenv("MIRT_REFILL_K")) { int k = atoi(e); if (k >= 1 && k <= 64) a.refill_k = k; }
 
   MIRT_HIP(hipEventRecord(sc->ev0, stream));
   if (count) MIRT_HIP(hipMemsetAsync(sc->counters, 0, 8 * sizeof(unsigned long long), stream));
   MIRT_HIP(hipEventRecord(sc->ev1, stream));
-  if (count) hipLaunchKernelGGL(trace_kernel<true>, dim3(blocks), dim3(RBLOCK), 0, stream, a);
-  else hipLaunchKernelGGL(trace_kernel<false>, dim3(blocks), dim3(RBLOCK), 0, stream, a);
+  const bool prof = getenv("MIRT_PROF") != nullptr;
+  if (prof) {
+    if (!sc->prof) MIRT_HIP(hipMalloc(&sc->prof, 16 * sizeof(unsigned long long)));
+    MIRT_HIP(hipMemsetAsync(sc->prof, 0, 16 * sizeof(unsigned long long), stream));
+    a.prof = sc->prof;
+    hipLaunchKernelGGL((trace_kernel<false, true>), dim3(blocks), dim3(RBLOCK), 0, stream, a);
+    MIRT_HIP(hipStreamSynchronize(stream));
+    unsigned long long h[16];
+    MIRT_HIP(hipMemcpy(h, sc->prof, sizeof(h), hipMemcpyDeviceToHost));
+    fprintf(stderr, "[mirt prof] waves=%llu cyc/wave=%.3g S=%.1f%% T=%.1f%% | T-iters/wave=%.0f active/iter=%.1f leaf-lanes/iter=%.1f | S-entries/wave=%.0f lanes/entry=%.1f | B-entries/wave=%.0f lanes/entry=%.1f\n",
+            h[10], (double)h[0] / h[10], 100.0 * h[1] / h[0], 100.0 * h[2] / h[0], (double)h[3] / h[10], (double)h[4] / (h[3] ? h[3] : 1), (double)h[9] / (h[3] ? h[3] : 1),
+            (double)h[5] / h[10], (double)h[6] / (h[5] ? h[5] : 1), (double)h[7] / h[10], (double)h[8] / (h[7] ? h[7] : 1));
+  } else if (count) hipLaunchKernelGGL((trace_kernel<true, false>), dim3(blocks), dim3(RBLOCK), 0, stream, a);
+  else hipLaunchKernelGGL((trace_kernel<false, false>), dim3(blocks), dim3(RBLOCK), 0, stream, a);
   MIRT_HIP(hipGetLastError());
   MIRT_HIP(hipEventRecord(sc->ev2, stream));
 

@@ -53,7 +53,10 @@ struct RenderArgs {
   uint32_t* stack_spill;          // [STACK_TOTAL - STACK_LDS][grid threads]
   float* pending;                 // [pending_slots][16 words][grid threads] or null
   int pending_slots;
+  int refill_k;                   // leave the traversal loop when this many lanes wait to shade
+  int batch_k;                    // start the next rays of ray batches when this many lanes wait for one
   unsigned long long* counters;   // MirtStats head (8 x u64) or null
+  unsigned long long* prof;       // diagnostic build only (MIRT_PROF)
 };
 
 struct ResolveArgs {
@@ -103,6 +106,7 @@ struct MirtScene {
   uint32_t* stack_spill = nullptr; size_t spill_cap = 0;
   float* pending = nullptr; size_t pending_cap = 0;
   unsigned long long* counters = nullptr;  // 8 x u64 on device
+  unsigned long long* prof = nullptr;      // diagnostic stamps (MIRT_PROF)
   // rng tables cache
   mirt::RngCache rng;
   // timing
