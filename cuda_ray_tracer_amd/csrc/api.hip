@@ -97,13 +97,31 @@ int mirt_scene_create(const MirtSceneDesc* d, int device, MirtScene** out)
 
   int rc = MIRT_OK;
   auto chk = [&](int r) { if (rc == MIRT_OK) rc = r; };
-  chk(upload(&sc->spheres, spheres)); chk(upload(&sc->tris, tris)); chk(upload(&sc->tri_verts, verts)); chk(upload(&sc->mats, mats));
+  // record heap: [internal nodes 64 B each | spheres 16 B | triangles 48 B | 64 B pad] -- the traversal kernel addresses
+  // any record with one 32-bit byte offset
+  {
+    const size_t nodes_bytes = N > 1 ? 64 * (size_t)(N - 1) : 0;
+    const size_t sph_bytes = 16 * (size_t)sc->Ns, tri_bytes = 48 * (size_t)sc->Nt;
+    const size_t total = nodes_bytes + sph_bytes + tri_bytes + 64;
+    if (total > 0xfffffff0ull) { delete sc; set_error("mirt_scene_create: scene too large for 32-bit record offsets"); return MIRT_ERR_ARG; }
+    hipError_t e = hipMalloc(&sc->heap, total);
+    if (e == hipSuccess) e = hipMemset(sc->heap, 0, total);
+    if (e != hipSuccess) { delete sc; return hip_fail(e, "hipMalloc(heap)", __FILE__, __LINE__); }
+    sc->sph_base = (uint32_t)nodes_bytes; sc->tri_base = (uint32_t)(nodes_bytes + sph_bytes);
+    sc->nodes = reinterpret_cast<float4*>(sc->heap);
+    sc->spheres = reinterpret_cast<float4*>(sc->heap + sc->sph_base);
+    sc->tris = reinterpret_cast<float4*>(sc->heap + sc->tri_base);
+    if (sph_bytes) e = hipMemcpy(sc->spheres, spheres.data(), sph_bytes, hipMemcpyHostToDevice);
+    if (e == hipSuccess && tri_bytes) e = hipMemcpy(sc->tris, tris.data(), tri_bytes, hipMemcpyHostToDevice);
+    if (e != hipSuccess) { mirt_scene_destroy(sc); return hip_fail(e, "hipMemcpy(heap)", __FILE__, __LINE__); }
+  }
+  chk(upload(&sc->tri_verts, verts)); chk(upload(&sc->mats, mats));
   chk(upload(&sc->refs_in, refs)); chk(upload(&sc->planes, planes)); chk(upload(&sc->suns, suns)); chk(upload(&sc->bulbs, bulbs));
   auto alloc = [&](void** p, size_t bytes) { if (rc == MIRT_OK && bytes) { hipError_t e = hipMalloc(p, bytes); if (e != hipSuccess) rc = hip_fail(e, "hipMalloc", __FILE__, __LINE__); } };
   if (N > 0) {
     alloc((void**)&sc->codes, 4 * (size_t)N); alloc((void**)&sc->order, 4 * (size_t)N);
     alloc((void**)&sc->parent, 4 * (2 * (size_t)N - 1)); alloc((void**)&sc->boxes, 24 * (2 * (size_t)N - 1));
-    if (N > 1) { alloc((void**)&sc->child_l, 4 * (size_t)(N - 1)); alloc((void**)&sc->child_r, 4 * (size_t)(N - 1)); alloc((void**)&sc->nodes, 64 * (size_t)(N - 1)); }
+    if (N > 1) { alloc((void**)&sc->child_l, 4 * (size_t)(N - 1)); alloc((void**)&sc->child_r, 4 * (size_t)(N - 1)); }
   }
   alloc((void**)&sc->bounds_keys, 6 * 4);
   alloc((void**)&sc->counters, 8 * sizeof(unsigned long long));
@@ -124,9 +142,9 @@ void mirt_scene_destroy(MirtScene* sc)
   if (!sc) return;
   hipSetDevice(sc->device);
   hipDeviceSynchronize();
-  hipFree(sc->spheres); hipFree(sc->tris); hipFree(sc->tri_verts); hipFree(sc->mats); hipFree(sc->refs_in);
+  hipFree(sc->heap); hipFree(sc->tri_verts); hipFree(sc->mats); hipFree(sc->refs_in);
   hipFree(sc->planes); hipFree(sc->suns); hipFree(sc->bulbs);
-  hipFree(sc->codes); hipFree(sc->order); hipFree(sc->child_l); hipFree(sc->child_r); hipFree(sc->parent); hipFree(sc->boxes); hipFree(sc->nodes);
+  hipFree(sc->codes); hipFree(sc->order); hipFree(sc->child_l); hipFree(sc->child_r); hipFree(sc->parent); hipFree(sc->boxes);
   hipFree(sc->bounds_keys); hipFree(sc->samples); hipFree(sc->stack_spill); hipFree(sc->pending); hipFree(sc->counters); hipFree(sc->prof);
   rng_cache_free(&sc->rng);
   if (sc->ev0) hipEventDestroy(sc->ev0);

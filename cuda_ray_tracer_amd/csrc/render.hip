@@ -33,6 +33,11 @@ constexpr int RBLOCK = 256;
 #endif
 constexpr int STACK_LDS = MIRT_STACK_LDS;
 constexpr int STACK_TOTAL = 64;      // TRAVERSAL_STACK_SIZE, bvh_traversal.cu:8
+#ifndef MIRT_QUAD_FETCH
+#define MIRT_QUAD_FETCH 0   // measured on MI355X: 77.5 ms vs 68.1 ms without (the LDS round trip adds latency; TA is not the limiter)
+#endif
+constexpr int STAGE_ROUND_BYTES = 64 * 16 + 16;          // +16: rounds land on different LDS bank phases (conflict-free ds_read_b128)
+constexpr int STAGE_WAVE_BYTES = MIRT_QUAD_FETCH ? 4 * STAGE_ROUND_BYTES : 0;
 constexpr int PENDING_WORDS = 16;
 
 constexpr float EPSILON = 0.001f;    // draw.cu:7, struct.cu:8
@@ -471,9 +476,13 @@ __global__ void __launch_bounds__(RBLOCK, MIRT_WAVES_PER_SIMD) trace_kernel(cons
   // PROF: diagnostic build only -- cycle stamps per phase, written to a.prof (never used for timing claims)
   unsigned long long pf_S = 0, pf_T = 0, pf_iters = 0, pf_active = 0, pf_Sent = 0, pf_Slanes = 0, pf_Bent = 0, pf_Blanes = 0, pf_leaf = 0, pf_node = 0;
   const unsigned long long pf_t0 = PROF ? clock64() : 0;
-  __shared__ uint32_t lds_stack[STACK_LDS * RBLOCK];
+  // One LDS array: [traversal stacks: STACK_LDS x RBLOCK words][per-wave record staging: 4 rounds x (64 x 16 B + 16 B pad)]
+  __shared__ __attribute__((aligned(16))) unsigned char lds_raw[STACK_LDS * RBLOCK * 4 + (RBLOCK / 64) * STAGE_WAVE_BYTES];
+  uint32_t* const lds_stack = reinterpret_cast<uint32_t*>(lds_raw);
   const int tid = threadIdx.x;
   const int lane = tid & 63;
+  unsigned char* const stage = lds_raw + STACK_LDS * RBLOCK * 4 + __builtin_amdgcn_readfirstlane(tid >> 6) * STAGE_WAVE_BYTES;
+  const unsigned char* const heap = reinterpret_cast<const unsigned char*>(a.nodes);
   const long long gid = (long long)blockIdx.x * RBLOCK + tid;
   const long long gthreads = (long long)gridDim.x * RBLOCK;
   Counters cn = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -541,16 +550,44 @@ __global__ void __launch_bounds__(RBLOCK, MIRT_WAVES_PER_SIMD) trace_kernel(cons
         if (!S.trav && S.batch_pending) batch_next<COUNT>(a, S, cn);
       }
       if (PROF) { pf_iters++; pf_active += __popcll(__ballot(S.trav)); pf_leaf += __popcll(__ballot(S.trav && (S.cur & REF_LEAF))); }
+#if MIRT_QUAD_FETCH
+      // Record fetch, cooperative over quads: in round j the four lanes of a quad bring the four 16-byte quarters of the
+      // record of quad-lane j's ray straight into LDS (one coalesced 64 B request instead of four divergent ones); each
+      // ray then reads its 64 bytes back with four conflict-free ds_read_b128.  All lanes take part (uniform control flow).
+      {
+        uint32_t off = 0xffffffffu;
+        if (S.trav) {
+          const uint32_t id0 = S.cur & REF_IDMASK;
+          off = (S.cur & REF_LEAF) ? ((S.cur & REF_TRI) ? a.tri_base + 48u * id0 : a.sph_base + 16u * id0) : 64u * S.cur;
+        }
+        const uint32_t sub = (uint32_t)(lane & 3) * 16u;
+#define MIRT_FETCH_ROUND(j)                                                                                                    \
+        {                                                                                                                      \
+          const uint32_t oj = (uint32_t)__builtin_amdgcn_mov_dpp((int)off, (j) | ((j) << 2) | ((j) << 4) | ((j) << 6), 0xf, 0xf, true); \
+          if (oj != 0xffffffffu)                                                                                               \
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(heap + oj + sub),                  \
+                                             (__attribute__((address_space(3))) void*)(stage + (j) * STAGE_ROUND_BYTES), 16, 0, 0); \
+        }
+        MIRT_FETCH_ROUND(0) MIRT_FETCH_ROUND(1) MIRT_FETCH_ROUND(2) MIRT_FETCH_ROUND(3)
+#undef MIRT_FETCH_ROUND
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+#endif
       if (S.trav) {
         // one fetch per iteration: the record `cur` names -- a node (4 x 16 B) or a primitive (sphere 16 B, triangle 48 B)
         const bool leaf = (S.cur & REF_LEAF) != 0;
         const bool tri = leaf && (S.cur & REF_TRI);
+#if MIRT_QUAD_FETCH
+        const float4* rec = reinterpret_cast<const float4*>(stage + (lane & 3) * STAGE_ROUND_BYTES + (lane & ~3) * 16);
+        const float4 q0 = rec[0], q1 = rec[1], q2 = rec[2], q3 = rec[3];
+#else
         const uint32_t id = S.cur & REF_IDMASK;
         const float4* rec = leaf ? (tri ? a.tris + 3 * (size_t)id : a.spheres + id) : a.nodes + 4 * (size_t)S.cur;
         const float4 q0 = rec[0];
         float4 q1 = make_float4(0, 0, 0, 0), q2 = q1, q3 = q1;
         if (!leaf || tri) { q1 = rec[1]; q2 = rec[2]; }
         if (!leaf) q3 = rec[3];
+#endif
         bool pop = false;
         if (leaf) {
           // intersect_leaf_primitives, bvh_traversal.cu:47-89
@@ -617,8 +654,8 @@ __global__ void __launch_bounds__(RBLOCK, MIRT_WAVES_PER_SIMD) trace_kernel(cons
             if (S.sp < STACK_TOTAL) {
               if (S.sp > 0) {
                 const int slot = S.sp - 1;
-                if (slot < STACK_LDS) lds_stack[slot * RBLOCK + tid] = S.tos;
-                else a.stack_spill[(size_t)(slot - STACK_LDS) * gthreads + gid] = S.tos;
+                if (slot < a.lds_depth) lds_stack[slot * RBLOCK + tid] = S.tos;
+                else a.stack_spill[(size_t)(slot - a.lds_depth) * gthreads + gid] = S.tos;
               }
               S.tos = rref;
               ++S.sp;
@@ -635,8 +672,8 @@ __global__ void __launch_bounds__(RBLOCK, MIRT_WAVES_PER_SIMD) trace_kernel(cons
             --S.sp;
             if (S.sp > 0) {
               const int slot = S.sp - 1;
-              S.tos = lds_stack[(slot < STACK_LDS ? slot : 0) * RBLOCK + tid];
-              if (slot >= STACK_LDS) S.tos = a.stack_spill[(size_t)(slot - STACK_LDS) * gthreads + gid];
+              S.tos = lds_stack[(slot < a.lds_depth ? slot : 0) * RBLOCK + tid];
+              if (slot >= a.lds_depth) S.tos = a.stack_spill[(size_t)(slot - a.lds_depth) * gthreads + gid];
             }
           }
         }
@@ -848,7 +885,7 @@ int render(MirtScene* sc, const MirtRenderParams* p, void* d_rgba8, void* d_rgba
     MIRT_HIP(hipMalloc(&sc->samples, sizeof(float4) * (size_t)nsamples));
     sc->samples_cap = (size_t)nsamples;
   }
-  const size_t spill_need = (size_t)(STACK_TOTAL - STACK_LDS) * gthreads;
+  const size_t spill_need = (size_t)STACK_TOTAL * gthreads;
   if (sc->spill_cap < spill_need) {
     MIRT_HIP(hipStreamSynchronize(stream));
     hipFree(sc->stack_spill); sc->stack_spill = nullptr; sc->spill_cap = 0;
@@ -878,6 +915,7 @@ int render(MirtScene* sc, const MirtRenderParams* p, void* d_rgba8, void* d_rgba
   a.num_local_pixels = npix; a.num_samples = nsamples;
   a.nodes = sc->nodes; a.spheres = sc->spheres; a.tris = sc->tris; a.mats = sc->mats;
   a.root_ref = sc->root_ref; a.num_spheres = sc->Ns; a.num_prims = sc->N;
+  a.sph_base = sc->sph_base; a.tri_base = sc->tri_base;
   a.planes = sc->planes; a.num_planes = sc->d.num_planes;
   a.suns = sc->suns; a.num_suns = sc->d.num_suns;
   a.bulbs = sc->bulbs; a.num_bulbs = sc->d.num_bulbs;
@@ -891,6 +929,8 @@ int render(MirtScene* sc, const MirtRenderParams* p, void* d_rgba8, void* d_rgba
   a.stack_spill = sc->stack_spill;
   a.pending = sc->pending; a.pending_slots = pending_slots;
   a.counters = count ? sc->counters : nullptr;
+  a.lds_depth = STACK_LDS;
+  if (const char* e = getenv("MIRT_STACK_LDS_DEPTH")) { int k = atoi(e); if (k >= 0 && k <= STACK_LDS) a.lds_depth = k; }   // tests: force the spill path
   a.refill_k = 32;
   a.batch_k = 8;
   if (const char* e = getenv("MIRT_BATCH_K")) { int k = atoi(e); if (k >= 1 && k <= 64) a.batch_k = k; }

@@ -40,6 +40,7 @@ struct RenderArgs {
   const float4* tris;             // 3 x float4: p0.xyz nor.x | nor.yz e1.xy | e1.z e2.xyz
   const float4* mats;             // 3 x float4 per primitive: spheres first, then triangles
   uint32_t root_ref;
+  uint32_t sph_base, tri_base;    // byte offsets of the sphere / triangle arrays in the record heap that starts at `nodes`
   int num_spheres;
   int num_prims;
   const PlaneDev* planes; int num_planes;
@@ -54,6 +55,7 @@ struct RenderArgs {
   float* pending;                 // [pending_slots][16 words][grid threads] or null
   int pending_slots;
   int refill_k;                   // leave the traversal loop when this many lanes wait to shade
+  int lds_depth;                  // traversal-stack entries kept in LDS (<= the compiled STACK_LDS); deeper ones spill
   int batch_k;                    // start the next rays of ray batches when this many lanes wait for one
   unsigned long long* counters;   // MirtStats head (8 x u64) or null
   unsigned long long* prof;       // diagnostic build only (MIRT_PROF)
@@ -96,7 +98,9 @@ struct MirtScene {
   uint32_t* child_r = nullptr;
   int* parent = nullptr;                // [2N-1]
   float* boxes = nullptr;               // [2N-1][6] xmin,xmax,ymin,ymax,zmin,zmax
-  float4* nodes = nullptr;              // packed [N-1][4]
+  float4* nodes = nullptr;              // packed [N-1][4]; start of the record heap [nodes | spheres | tris | pad]
+  unsigned char* heap = nullptr;
+  uint32_t sph_base = 0, tri_base = 0;
   uint32_t* bounds_keys = nullptr;      // [6] ordered-uint min xyz, max xyz
   uint32_t root_ref = mirt::REF_NONE;
   bool built = false;

@@ -1,0 +1,105 @@
+"""Small synthetic scenes for the edge cases the bundled files do not reach (test data, generated not stored)."""
+import numpy as np
+
+HEADER = "png 64 48 edge.png\n"
+
+
+def bulbs_and_planes():
+    return HEADER + """bounces 3
+color 1 0.9 0.8
+bulb 0 3 1
+color 0.2 0.4 1
+bulb -2 1 0.5
+color 1 1 1
+sun 0.3 1 0.2
+color 0.7 0.7 0.7
+plane 0 1 0 1
+color 0.5 0.6 0.7
+shininess 0.3
+plane 0 0 1 6
+color 1 0.3 0.2
+shininess 0.5
+roughness 0.1
+sphere 0 0 -3 1
+color 0.2 1 0.3
+shininess 0
+sphere 1.5 -0.5 -2.5 0.5
+xyz -2 -1 -4
+xyz 2 -1 -4
+xyz 0 2 -5
+color 0.9 0.9 0.2
+tri 1 2 3
+"""
+
+
+def fisheye():
+    return HEADER + "fisheye\nforward 0 0 -0.6\n" + "color 1 1 1\nsun 1 1 1\nsphere 0 0 -2 0.7\nsphere 1 0.5 -1.5 0.3\nplane 0 1 0 1\n"
+
+
+def panorama():
+    return HEADER + "panorama\neye 0 0.2 0\n" + "color 1 1 1\nsun 1 1 1\ncolor 1 0 0\nsphere 0 0 -2 0.7\ncolor 0 1 0\nsphere 2 0 0 0.7\ncolor 0 0 1\nsphere 0 0 2 0.7\nplane 0 1 0 1\n"
+
+
+def empty():
+    return HEADER + "color 1 1 1\nsun 0 1 0\n"
+
+
+def plane_only():
+    return HEADER + "color 1 1 1\nsun 0 1 0.2\ncolor 0.4 0.5 0.6\nshininess 0.5\nplane 0 1 0 1\n"
+
+
+def single_sphere():
+    return HEADER + "color 1 1 1\nsun 1 1 1\nshininess 0.4\nsphere 0 0 -2 0.8\n"
+
+
+def single_triangle():
+    return HEADER + "color 1 1 1\nsun 0 0 1\nxyz -1 -1 -2\nxyz 1 -1 -2\nxyz 0 1 -2\ntri 1 2 3\n"
+
+
+def zero_bounces():
+    return HEADER + "bounces 0\ncolor 1 1 1\nsun 1 1 1\nsphere 0 0 -2 0.8\n"
+
+
+def one_bounce_glass_gi():
+    return HEADER + """bounces 5
+gi 2
+expose 1.5
+dof 2.0 0.05
+color 1 1 1
+sun 1 1 0.5
+color 0.3 0.3 0.3
+plane 0 1 0 1
+color 1 1 1
+transparency 0.9
+shininess 0.1
+ior 1.3
+sphere 0 0 -2 0.7
+transparency 0 0.5 0
+shininess 0.6 0.2 0.1
+roughness 0.2
+color 0.9 0.4 0.1
+sphere 1.2 0 -2.5 0.5
+transparency 0
+shininess 0
+color 0.2 0.3 0.9
+xyz -3 -1 -5
+xyz 3 -1 -5
+xyz 0 3 -5
+tri -3 -2 -1
+"""
+
+
+def deep_stack(n=3000):
+    """n concentric, slightly shifted spheres: every box overlaps every other, so rays push at every level of a tree that
+    the duplicate-code tie-break makes deep; exercises stack depths beyond the LDS part of the traversal stack."""
+    rng = np.random.default_rng(7)
+    lines = [HEADER, "color 1 1 1\nsun 1 1 1\nbounces 2\nshininess 0.2\n"]
+    for i in range(n):
+        r = 0.5 + 0.4 * rng.random()
+        lines.append(f"sphere {1e-5 * rng.standard_normal():.8f} {1e-5 * rng.standard_normal():.8f} {-3 + 1e-5 * rng.standard_normal():.8f} {r:.6f}\n")
+    return "".join(lines)
+
+
+ALL = {"bulbs_and_planes": bulbs_and_planes, "fisheye": fisheye, "panorama": panorama, "empty": empty, "plane_only": plane_only,
+       "single_sphere": single_sphere, "single_triangle": single_triangle, "zero_bounces": zero_bounces,
+       "glass_gi_dof": one_bounce_glass_gi, "deep_stack": deep_stack}

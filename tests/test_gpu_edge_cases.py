@@ -1,0 +1,81 @@
+"""GPU parity on synthetic edge-case scenes: bulbs, several planes, fisheye / panorama cameras, empty scene, N = 1,
+bounces 0, glass + GI + exposure + depth of field, and a tree deep enough to use the stack spill path."""
+import numpy as np
+import pytest
+import torch
+
+import cuda_ray_tracer_amd as m
+from cuda_ray_tracer_amd import api
+import oracle_lib as ol
+import pyscene
+import edge_scenes
+
+pytestmark = pytest.mark.gpu
+
+
+def run_case(text, w, h, spp):
+    stl = m.parseText(text)
+    raw = m.initRawConfigFromStl(stl, 0)
+    m.build_lbvh_karas(raw)
+    p = api.render_params(w, h, spp, counters=True)
+    img = torch.empty(w * h * 4, dtype=torch.uint8, device="cuda")
+    flt = torch.empty(w * h * 4, dtype=torch.float32, device="cuda")
+    m.render(img, w, h, spp, raw, d_float=flt, params=p)
+    torch.cuda.synchronize()
+    st = raw.stats()
+    tree = raw.tree() if stl.num_prims > 0 else None
+    raw.close()
+    o = ol.OracleScene(pyscene.parse_lines(text.split("\n")), bounds_mode=0)
+    ref = o.render(w, h, spp, flags=ol.FLAG_ANYHIT_SHADOW, nthreads=8)
+    if tree is not None:
+        on = o.nodes()
+        for f in ("left", "right"):
+            assert np.array_equal(tree[0][f], on[f]), f
+    o.close()
+    gf, gu = flt.cpu().numpy().reshape(h, w, 4), img.cpu().numpy().reshape(h, w, 4)
+    both_nan = np.isnan(gf) & np.isnan(ref["f32"])
+    d = np.where(both_nan, 0.0, np.abs(gf.astype(np.float64) - ref["f32"].astype(np.float64)))
+    assert np.array_equal(np.isnan(gf), np.isnan(ref["f32"]))
+    assert np.nanmax(d) <= 1e-4, float(np.nanmax(d))
+    assert np.abs(gu.astype(np.int32) - ref["u8"].astype(np.int32)).max() <= 1
+    for k in ("samples", "rays", "shadow_rays", "internal_visits", "sphere_tests", "tri_tests", "mat_fetches", "max_stack"):
+        assert st[k] == ref["stats"][k], (k, st[k], ref["stats"][k])
+    return st, gu
+
+
+@pytest.mark.parametrize("name", [n for n in edge_scenes.ALL if n != "deep_stack"])
+@pytest.mark.parametrize("spp", [0, 1, 8])
+def test_edge_scene_matches_oracle(name, spp):
+    st, img = run_case(edge_scenes.ALL[name](), 64, 48, spp)
+    if name == "empty":
+        assert img.max() == 0
+    if name in ("plane_only", "single_sphere", "bulbs_and_planes"):
+        assert img[..., 3].max() == 255
+
+
+def test_stack_spill_path(monkeypatch):
+    """Stack depths beyond 32 LDS entries + the top-of-stack register need > 2^33 overlapping primitives in a balanced
+    Karras tree, so the spill path is forced instead: with MIRT_STACK_LDS_DEPTH=2 every entry below the top three goes
+    to the global spill area (max depth on this scene: 12).  Results and counters must not change."""
+    monkeypatch.setenv("MIRT_STACK_LDS_DEPTH", "2")
+    st, img = run_case(edge_scenes.deep_stack(3000), 24, 18, 4)
+    assert st["max_stack"] >= 10, st["max_stack"]
+    monkeypatch.setenv("MIRT_STACK_LDS_DEPTH", "0")
+    run_case(edge_scenes.deep_stack(500), 16, 12, 1)
+
+
+def test_more_than_64_lights_is_rejected():
+    text = edge_scenes.HEADER + "".join(f"sun {i + 1} 1 1\n" for i in range(65)) + "sphere 0 0 -2 1\n"
+    stl = m.parseText(text)
+    with pytest.raises(m.MirtError):
+        m.initRawConfigFromStl(stl, 0)
+
+
+def test_render_before_build_is_an_error():
+    stl = m.parseText(edge_scenes.single_sphere())
+    raw = m.initRawConfigFromStl(stl, 0)
+    img = torch.empty(16 * 16 * 4, dtype=torch.uint8, device="cuda")
+    with pytest.raises(m.MirtError) as e:
+        m.render(img, 16, 16, 1, raw)
+    assert e.value.status == 6
+    raw.close()
