@@ -17,7 +17,7 @@ LIB = os.path.join(OUT, "libmirt.so")
 CLI = os.path.join(OUT, "raytracer")
 ARCH = "gfx950"
 
-LIB_SOURCES = ["host_scene.cpp", "png_writer.cpp", "xorwow_tables.cpp", "lbvh_build.hip", "render.hip", "api.hip"]
+LIB_SOURCES = ["host_scene.cpp", "png_writer.cpp", "xorwow_tables.cpp", "lbvh_build.hip", "render.hip", "wavefront.hip", "api.hip"]
 COMMON = ["-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math", "-Wall", "-Wno-unused-function", "-Wno-unused-value", "-Wno-unused-result",
           f"--offload-arch={ARCH}", "-fno-gpu-flush-denormals-to-zero"]
 
@@ -48,7 +48,7 @@ def build(force=False, verbose=False):
     hipcc = _hipcc()
     deps = _all_deps()
     extra = []
-    for var in ("MIRT_WAVES_PER_SIMD", "MIRT_STACK_LDS"):      # tuning experiments only; defaults live in render.hip
+    for var in ("MIRT_WAVES_PER_SIMD", "MIRT_STACK_LDS", "MIRT_WF_WAVES_PER_SIMD", "MIRT_WF_SHADE_WAVES", "MIRT_WF_QUAD_FETCH", "MIRT_DEFAULT_WAVEFRONT"):      # tuning experiments only; defaults live in render.hip
         if os.environ.get(var):
             extra.append(f"-D{var}=" + os.environ[var])
     objs = []

@@ -147,6 +147,9 @@ void mirt_scene_destroy(MirtScene* sc)
   hipFree(sc->codes); hipFree(sc->order); hipFree(sc->child_l); hipFree(sc->child_r); hipFree(sc->parent); hipFree(sc->boxes);
   hipFree(sc->bounds_keys); hipFree(sc->samples); hipFree(sc->stack_spill); hipFree(sc->pending); hipFree(sc->counters); hipFree(sc->prof);
   rng_cache_free(&sc->rng);
+  hipFree(sc->wf_state); hipFree(sc->wf_rays); hipFree(sc->wf_ctr);
+  if (sc->wf_ctr_host) hipHostFree(sc->wf_ctr_host);
+  for (hipEvent_t e : sc->wf_events) hipEventDestroy(e);
   if (sc->ev0) hipEventDestroy(sc->ev0);
   if (sc->ev1) hipEventDestroy(sc->ev1);
   if (sc->ev2) hipEventDestroy(sc->ev2);
@@ -188,6 +191,7 @@ int mirt_get_stats(MirtScene* sc, MirtStats* out)
   if (!sc->have_render) return MIRT_OK;
   MIRT_HIP(hipEventSynchronize(sc->ev3));
   MIRT_HIP(hipEventElapsedTime(&out->trace_kernel_ms, sc->ev1, sc->ev2));
+  if (sc->wf_trace_ms >= 0.0f) out->trace_kernel_ms = sc->wf_trace_ms;
   MIRT_HIP(hipEventElapsedTime(&out->render_ms, sc->ev0, sc->ev3));
   if (sc->last_counted) {
     unsigned long long c[8];

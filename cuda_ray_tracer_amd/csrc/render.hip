@@ -14,6 +14,7 @@
 // reference's bottom-up recursion; geometry and random-number consumption are identical, colours agree to rounding.
 #include "scene_dev.h"
 #include "host_scene.h"
+#include "shade_common.h"
 
 #include <climits>
 #include <cmath>
@@ -25,6 +26,9 @@ namespace mirt {
 namespace {
 
 constexpr int RBLOCK = 256;
+#ifndef MIRT_DEFAULT_WAVEFRONT
+#define MIRT_DEFAULT_WAVEFRONT 0
+#endif
 #ifndef MIRT_WAVES_PER_SIMD
 #define MIRT_WAVES_PER_SIMD 4   // 128 VGPRs: measured best (2: 86 ms, 3: 76 ms, 4: 68 ms, 5: 79 ms on tenthousand 1080p16)
 #endif
@@ -32,444 +36,11 @@ constexpr int RBLOCK = 256;
 #define MIRT_STACK_LDS 32
 #endif
 constexpr int STACK_LDS = MIRT_STACK_LDS;
-constexpr int STACK_TOTAL = 64;      // TRAVERSAL_STACK_SIZE, bvh_traversal.cu:8
 #ifndef MIRT_QUAD_FETCH
 #define MIRT_QUAD_FETCH 0   // measured on MI355X: 77.5 ms vs 68.1 ms without (the LDS round trip adds latency; TA is not the limiter)
 #endif
 constexpr int STAGE_ROUND_BYTES = 64 * 16 + 16;          // +16: rounds land on different LDS bank phases (conflict-free ds_read_b128)
 constexpr int STAGE_WAVE_BYTES = MIRT_QUAD_FETCH ? 4 * STAGE_ROUND_BYTES : 0;
-constexpr int PENDING_WORDS = 16;
-
-constexpr float EPSILON = 0.001f;    // draw.cu:7, struct.cu:8
-
-enum : int { ST_PRIMARY = 0, ST_BATCH, ST_REFR_INSIDE, ST_REFR_FINAL, ST_GI };
-enum : int { M_BATCH = 0, M_POP, M_TRACE, M_DONE };
-enum : uint32_t { PEND_F = 1u, PEND_G = 2u };
-
-struct Mat { f3 color, shininess, trans; float ior, roughness; };
-
-MIRT_DEV Mat load_mat(const float4* __restrict__ mats, uint32_t idx)
-{
-  const float4 a = mats[3 * (size_t)idx + 0], b = mats[3 * (size_t)idx + 1], c = mats[3 * (size_t)idx + 2];
-  Mat m;
-  m.color = mk3(a.x, a.y, a.z); m.shininess = mk3(a.w, b.x, b.y); m.trans = mk3(b.z, b.w, c.x); m.ior = c.y; m.roughness = c.z;
-  return m;
-}
-MIRT_DEV Mat plane_mat(const PlaneDev& p)
-{
-  Mat m;
-  m.color = mk3(p.mat[0], p.mat[1], p.mat[2]); m.shininess = mk3(p.mat[3], p.mat[4], p.mat[5]); m.trans = mk3(p.mat[6], p.mat[7], p.mat[8]);
-  m.ior = p.mat[9]; m.roughness = p.mat[10];
-  return m;
-}
-
-// setExpose, helper.cu:40-45 (the subtraction is in double)
-MIRT_DEV float set_expose(float c, float expose)
-{
-  if (expose == INFINITY) return c;
-  return (float)(1.0 - (double)dm_expf(-expose * c));
-}
-
-// Ray(eye, dir, bounce) normalises dir, object.cuh:69
-struct RayS { f3 o, d; int bounce; };
-MIRT_DEV RayS mkray(const f3& o, const f3& d, int bounce) { RayS r; r.o = o; r.d = normalize(d); r.bounce = bounce; return r; }
-
-// Ray::Ray(x, y, state, config), struct.cu:16-62
-MIRT_DEV RayS primary_ray(const RenderArgs& a, float x, float y, Xorwow& rng)
-{
-  const float PI = 3.14159265358979323846f;
-  const float max_dim = fmaxf((float)a.width, (float)a.height);
-  float sx = (2.0f * x - (float)a.width) / max_dim;
-  float sy = ((float)a.height - 2.0f * y) / max_dim;
-  RayS r;
-  r.o = a.eye;
-  f3 dir;
-  if (a.fisheye) {
-    dir = (sx * a.right + sy * a.up) + sqrtf(1.0f - (sx * sx) - (sy * sy)) * a.forward;
-  } else if (a.panorama) {
-    sx = x / (float)a.width;
-    sy = y / (float)a.height;
-    const float theta = (sx - 0.5f) * 2.0f * PI;
-    const float phi = (sy - 0.5f) * PI;
-    dir = dm_cosf(phi) * (dm_cosf(theta) * a.forward + dm_sinf(theta) * a.right) - dm_sinf(phi) * a.up;
-    dir = normalize(dir);
-  } else if (a.dof_focus != 0.0f) {
-    const float theta = randD(0.0f, 2.0f * PI, rng);
-    const float rr = randD(0.0f, a.dof_lens, rng);
-    const float lx = rr * dm_cosf(theta);
-    const float ly = rr * dm_sinf(theta);
-    r.o = r.o + lx * a.up + ly * a.right;
-    const f3 old_dir = a.forward + sx * a.right + sy * a.up;
-    dir = (a.eye + normalize(old_dir) * a.dof_focus - r.o) / a.dof_focus;
-  } else {
-    dir = a.forward + sx * a.right + sy * a.up;
-  }
-  r.bounce = a.bounces;
-  r.d = normalize(dir);
-  return r;
-}
-
-// spherePoint, helper.cu:91-101
-MIRT_DEV f3 sphere_point(Xorwow& rng)
-{
-  const float z = 2.0f * randD(0.0f, 1.0f, rng) - 1.0f;
-  const float theta = 2.0f * 3.14159265f * randD(0.0f, 1.0f, rng);
-  const float r = sqrtf(1.0f - z * z);
-  const float x = r * dm_cosf(theta);
-  const float y = r * dm_sinf(theta);
-  return mk3(x, y, z);
-}
-
-// draw.cu:333-338 / 393-398 (argument evaluation order: left to right)
-MIRT_DEV f3 rough_normal(const f3& n, float roughness, Xorwow& rng)
-{
-  const float a = standerdD(roughness, rng);
-  const float b = standerdD(roughness, rng);
-  const float c = standerdD(roughness, rng);
-  return n + mk3(a, b, c);
-}
-
-struct Counters { uint32_t samples, rays, shadow_rays, internal_visits, sphere_tests, tri_tests, mat_fetches, max_stack; };
-
-// Everything a lane carries from one loop iteration to the next.
-struct Lane {
-  // sample being evaluated (g < 0: none)
-  long long g;
-  Xorwow rng;
-  f3 L;
-  float alpha;
-  // current shading node H: the ray that produced it and the hit
-  f3 Hdir, Hp, Hn, Hcolor;
-  int Hbounce;
-  float Hior, Hrough;
-  bool HtransNZ;
-  f3 wt, wD, pn;
-  int pc, refr_bounce, gi_n, state;
-  // the node's ray batch: shadow rays to every light, then the reflection ray; all leave from bo
-  f3 bo, rdir;
-  int li;                      // index of the batch ray in flight: < nlights shadow, == nlights reflection
-  unsigned long long occl;     // bit i: light i is occluded
-  bool batch_pending, has_reflect;
-  // ray in flight
-  f3 o, d, inv;
-  int bounce;
-  float limit;        // shadow rays: occluded iff something is hit closer than this
-  bool shadow;
-  float tplane;
-  int plane_id;
-  // traversal
-  bool trav;
-  uint32_t cur;
-  uint32_t tos;       // top of the traversal stack (entries below it live in LDS / the spill area)
-  int sp;
-  float tbest;
-  uint32_t refbest;
-};
-
-// hitNearest's plane half (checkPlane, draw.cu:581-615) and the decision whether the BVH must be walked at all.
-template <bool COUNT>
-MIRT_DEV void start_ray(const RenderArgs& a, Lane& S, Counters& cn)
-{
-  const bool shadow = S.shadow;
-  if (COUNT) { cn.rays++; if (shadow) cn.shadow_rays++; }
-  S.inv = mk3(1.0f / S.d.x, 1.0f / S.d.y, 1.0f / S.d.z);
-  float tplane = INFINITY;
-  int plane_id = -1;
-  for (int i = 0; i < a.num_planes; ++i) {
-    const PlaneDev& pl = a.planes[i];
-    const f3 pnor = mk3(pl.nx, pl.ny, pl.nz);
-    const float t = dot(mk3(pl.px, pl.py, pl.pz) - S.o, pnor) / dot(S.d, pnor);
-    if (t <= 1e-6f) continue;
-    if (t < tplane && t > EPSILON) { tplane = t; plane_id = i; }
-  }
-  if (tplane >= (float)(INT_MAX - 10)) { tplane = INFINITY; plane_id = -1; }
-  S.tplane = tplane; S.plane_id = plane_id;
-  S.tbest = INFINITY; S.refbest = REF_NONE;
-  S.cur = a.root_ref; S.sp = 0;
-  // a shadow ray the plane already blocks needs no traversal (same boolean as draw.cu:347-352 / 365-370)
-  S.trav = (a.root_ref != REF_NONE) && !(shadow && plane_id >= 0 && tplane < S.limit);
-}
-
-MIRT_DEV void set_ray(Lane& S, const RayS& r) { S.o = r.o; S.d = r.d; S.bounce = r.bounce; }
-
-// The ray of the batch that was in flight has finished: note a shadow result, start the next ray of the batch
-// (shadow rays of diffuseLight, draw.cu:342-374, then the reflection ray of reflectionLight, draw.cu:402-404).
-// Shadow rays consume no random numbers, so tracing them after the reflection direction was drawn changes nothing.
-template <bool COUNT>
-MIRT_DEV void batch_next(const RenderArgs& a, Lane& S, Counters& cn)
-{
-  const int nlights = a.num_suns + a.num_bulbs;
-  if (S.li >= 0 && S.li < nlights) {
-    const bool occluded = (S.plane_id >= 0 && S.tplane < S.limit) || (S.refbest != REF_NONE && S.tbest < S.limit);
-    if (occluded) S.occl |= 1ull << S.li;
-  }
-  ++S.li;
-  if (S.li < nlights) {
-    // shadow ray, draw.cu:346 / 362-363
-    if (S.li < a.num_suns) {
-      const LightDev& lt = a.suns[S.li];
-      set_ray(S, mkray(S.bo, mk3(lt.x, lt.y, lt.z), 1));
-      S.limit = INFINITY;
-    } else {
-      const LightDev& lt = a.bulbs[S.li - a.num_suns];
-      const f3 bd = mk3(lt.x, lt.y, lt.z) - S.Hp;
-      set_ray(S, mkray(S.bo, bd, 1));
-      S.limit = length(bd);
-    }
-    S.shadow = true;
-    start_ray<COUNT>(a, S, cn);
-  } else if (S.li == nlights && S.has_reflect) {
-    S.o = S.bo; S.d = S.rdir; S.bounce = S.Hbounce - 1;
-    S.shadow = false;
-    S.limit = INFINITY;
-    start_ray<COUNT>(a, S, cn);
-  } else {
-    S.batch_pending = false;
-    S.shadow = false;
-    S.trav = false;
-  }
-}
-
-// Consume the finished trace of lane S and run its shading state machine until it either has the next ray
-// (S.trav / result pending again) or the sample is complete (S.g = -1 after the RGBA is written).
-template <bool COUNT>
-MIRT_DEV void advance(const RenderArgs& a, Lane& S, Counters& cn, const long long gid, const long long gthreads)
-{
-  const int nlights = a.num_suns + a.num_bulbs;
-  int micro = M_TRACE;
-  const bool bvh_hit = S.refbest != REF_NONE;
-  const bool pl_hit = S.plane_id >= 0;
-  const f3 rd0 = S.d, ro0 = S.o;
-  bool no_ray = false;     // the node had no reflection ray: nothing was traced, treat as a miss
-  if (S.state == ST_BATCH) {
-    // diffuseLight's light loops (draw.cu:342-374) with the occlusion bits the batch collected
-    f3 Dacc = mk3(0.0f, 0.0f, 0.0f);
-    for (int li = 0; li < nlights; ++li) {
-      if ((S.occl >> li) & 1ull) continue;
-      if (li < a.num_suns) {
-        const LightDev& lt = a.suns[li];
-        const float lambert = fmaxf(dot(S.pn, normalize(mk3(lt.x, lt.y, lt.z))), 0.0f);
-        const float r = S.Hcolor.x * (lt.r * lambert), gg = S.Hcolor.y * (lt.g * lambert), b = S.Hcolor.z * (lt.b * lambert);
-        Dacc = Dacc + mk3(set_expose(r, a.expose), set_expose(gg, a.expose), set_expose(b, a.expose));
-      } else {
-        const LightDev& lt = a.bulbs[li - a.num_suns];
-        const f3 bd = mk3(lt.x, lt.y, lt.z) - S.Hp;
-        const float lambert = fmaxf(dot(S.pn, normalize(bd)), 0.0f);
-        const float tl = length(bd);
-        const float inv2 = 1.0f / (tl * tl);
-        const float r = S.Hcolor.x * (lt.r * lambert), gg = S.Hcolor.y * (lt.g * lambert), b = S.Hcolor.z * (lt.b * lambert);
-        Dacc = Dacc + mk3(set_expose(r, a.expose) * inv2, set_expose(gg, a.expose) * inv2, set_expose(b, a.expose) * inv2);
-      }
-    }
-    S.L = S.L + S.wD * Dacc;
-    no_ray = !S.has_reflect;
-  }
-  {
-    // hitNearest, draw.cu:292-318: the nearer of BVH hit and plane hit (the plane wins an exact tie)
-    const bool use_bvh = !no_ray && bvh_hit && (!pl_hit || S.tbest < S.tplane);
-    const bool hit = !no_ray && (bvh_hit || pl_hit);
-    f3 Np = mk3(0, 0, 0), Nn = mk3(0, 0, 0);
-    Mat nm;
-    nm.color = mk3(0, 0, 0); nm.shininess = mk3(0, 0, 0); nm.trans = mk3(0, 0, 0); nm.ior = 1.458f; nm.roughness = 0.0f;
-    if (use_bvh) {
-      const uint32_t id = S.refbest & REF_IDMASK;
-      Np = S.tbest * rd0 + ro0;
-      if (S.refbest & REF_TRI) {
-        const float4 q0 = a.tris[3 * (size_t)id + 0], q1 = a.tris[3 * (size_t)id + 1];
-        const f3 nor = mk3(q0.w, q1.x, q1.y);
-        const float denom = dot(rd0, nor);
-        Nn = (denom < 0.0f) ? nor : -nor;
-        nm = load_mat(a.mats, (uint32_t)a.num_spheres + id);
-      } else {
-        const float4 s = a.spheres[id];
-        const f3 c = mk3(s.x, s.y, s.z);
-        const f3 cr0 = c - ro0;
-        const bool inside = (dot(cr0, cr0) < s.w * s.w);
-        Nn = normalize(inside ? (c - Np) : (Np - c));
-        nm = load_mat(a.mats, id);
-      }
-      if (COUNT) cn.mat_fetches++;
-    } else if (hit) {
-      const PlaneDev& pl = a.planes[S.plane_id];
-      const f3 pnor = mk3(pl.nx, pl.ny, pl.nz);
-      Np = S.tplane * rd0 + ro0;
-      Nn = (dot(pnor, rd0) < 0.0f) ? pnor : -pnor;
-      nm = plane_mat(pl);
-    }
-
-    if (S.state == ST_REFR_INSIDE) {
-      // second half of refractionLight, draw.cu:484-493.  No miss check: a miss yields the default ObjectInfo
-      // (normal 0, ior 1.458, point 0), which is what Np/Nn/nm hold then.
-      const f3 normal = normalize(Nn);
-      const float ior = nm.ior;
-      const float dn = dot(normal, rd0);
-      const float k = 1.0f - ior * ior * (1.0f - (dn * dn));
-      const f3 rd = ior * rd0 - (ior * (dot(normal, rd0)) + sqrtf(k)) * normal;
-      set_ray(S, mkray(Np - normal * 0.0001f, rd, S.refr_bounce - 1));
-      S.state = ST_REFR_FINAL;
-      micro = (S.bounce == 0) ? M_POP : M_TRACE;
-    } else if (!hit) {
-      // primary miss: RGBA(0,0,0,0) (draw.cu:267,284).  A secondary miss contributes nothing to rgb.
-      micro = (S.state == ST_PRIMARY) ? M_DONE : M_POP;
-    } else {
-      // refraction arguments X of the node being entered: the parent's H after a reflection (draw.cu:424), else H itself
-      f3 Xdir, Xp, Xn;
-      int Xbounce;
-      float Xior;
-      bool XtransNZ, x_parent = false, has_gi = false;
-      if (S.state == ST_PRIMARY) { S.alpha = 1.0f; S.wt = mk3(1.0f, 1.0f, 1.0f); has_gi = true; S.gi_n = a.gi; }
-      else if (S.state == ST_BATCH) x_parent = true;
-      else if (S.state == ST_GI) has_gi = true;     // gi_n was set when the ray was made
-      Xdir = S.Hdir; Xbounce = S.Hbounce; Xp = S.Hp; Xn = S.Hn; Xior = S.Hior; XtransNZ = S.HtransNZ;
-      S.Hdir = rd0; S.Hbounce = S.bounce; S.Hp = Np; S.Hn = Nn;
-      S.Hcolor = nm.color; S.Hior = nm.ior; S.Hrough = nm.roughness; S.HtransNZ = !is_black(nm.trans);
-      if (!x_parent) { Xdir = S.Hdir; Xbounce = S.Hbounce; Xp = S.Hp; Xn = S.Hn; Xior = S.Hior; XtransNZ = S.HtransNZ; }
-      // weights of this node's terms (draw.cu:277-281, 426-428, 517-519, 561-563)
-      const f3 one = mk3(1.0f, 1.0f, 1.0f);
-      const f3 Sh = nm.shininess, T = nm.trans;
-      const f3 K = (one - Sh) * (one - T);
-      if (has_gi && a.gi != 0 && S.gi_n != 0 && S.pc < a.pending_slots) {
-        const f3 w = (S.wt * K) * nm.color;
-        float* e = a.pending + ((size_t)S.pc * PENDING_WORDS) * gthreads + gid;
-        e[0 * gthreads] = __uint_as_float(PEND_G);
-        e[1 * gthreads] = S.Hp.x; e[2 * gthreads] = S.Hp.y; e[3 * gthreads] = S.Hp.z;
-        e[4 * gthreads] = S.Hn.x; e[5 * gthreads] = S.Hn.y; e[6 * gthreads] = S.Hn.z;
-        e[7 * gthreads] = __int_as_float(S.gi_n);
-        e[8 * gthreads] = w.x; e[9 * gthreads] = w.y; e[10 * gthreads] = w.z;
-        ++S.pc;
-      }
-      if (XtransNZ && Xbounce > 0 && S.pc < a.pending_slots) {
-        const f3 w = S.wt * ((one - Sh) * T);
-        float* e = a.pending + ((size_t)S.pc * PENDING_WORDS) * gthreads + gid;
-        e[0 * gthreads] = __uint_as_float(PEND_F);
-        e[1 * gthreads] = Xp.x; e[2 * gthreads] = Xp.y; e[3 * gthreads] = Xp.z;
-        e[4 * gthreads] = Xn.x; e[5 * gthreads] = Xn.y; e[6 * gthreads] = Xn.z;
-        e[7 * gthreads] = __int_as_float(Xbounce);
-        e[8 * gthreads] = w.x; e[9 * gthreads] = w.y; e[10 * gthreads] = w.z;
-        e[11 * gthreads] = Xdir.x; e[12 * gthreads] = Xdir.y; e[13 * gthreads] = Xdir.z;
-        e[14 * gthreads] = Xior;
-        ++S.pc;
-      }
-      S.wD = S.wt * K;
-      S.wt = S.wt * Sh;
-      const bool reflect_ok = !is_black(Sh) && S.Hbounce > 0;
-      // diffuseLight prologue, draw.cu:331-340
-      S.pn = S.Hn;
-      if (S.Hrough > 0.0f) S.pn = rough_normal(S.Hn, S.Hrough, S.rng);
-      S.pn = normalize(S.pn);
-      // reflectionLight prologue, draw.cu:389-402 (its draws follow diffuseLight's; the shadow rays in between draw nothing)
-      S.has_reflect = false;
-      if (reflect_ok) {
-        f3 normal = S.Hn;
-        if (S.Hrough > 0.0f) normal = rough_normal(S.Hn, S.Hrough, S.rng);
-        normal = normalize(normal);
-        S.rdir = normalize(S.Hdir - 2.0f * (dot(normal, S.Hdir)) * normal);
-        S.has_reflect = (S.Hbounce - 1) != 0;      // a bounce-0 ray never hits (draw.cu:294)
-      }
-      S.bo = S.Hp + S.Hn * EPSILON;
-      S.occl = 0ull;
-      S.li = -1;
-      S.batch_pending = true;
-      S.state = ST_BATCH;
-      micro = M_BATCH;
-    }
-  }
-
-  // run the micro-states until this lane has a ray or is finished
-  while (micro == M_POP) {
-    {
-      if (S.pc == 0) micro = M_DONE;
-      else {
-        --S.pc;
-        const float* e = a.pending + ((size_t)S.pc * PENDING_WORDS) * gthreads + gid;
-        const uint32_t tag = __float_as_uint(e[0 * gthreads]);
-        const f3 p = mk3(e[1 * gthreads], e[2 * gthreads], e[3 * gthreads]);
-        const f3 n = mk3(e[4 * gthreads], e[5 * gthreads], e[6 * gthreads]);
-        const int ib = __float_as_int(e[7 * gthreads]);
-        S.wt = mk3(e[8 * gthreads], e[9 * gthreads], e[10 * gthreads]);
-        if (tag == PEND_G) {
-          // globalIllumination, draw.cu:540-549
-          const f3 gi_dir = normalize(n + sphere_point(S.rng));
-          set_ray(S, mkray(p + n * EPSILON, gi_dir, ib - 1));
-          S.gi_n = ib - 1;
-          S.state = ST_GI;
-          micro = (S.bounce == 0) ? M_POP : M_TRACE;
-        } else {
-          // refractionLight, draw.cu:456-480
-          const f3 dir = mk3(e[11 * gthreads], e[12 * gthreads], e[13 * gthreads]);
-          const float ior = 1.0f / e[14 * gthreads];
-          const f3 normal = normalize(n);
-          const float dn = dot(normal, dir);
-          const float k = 1.0f - (ior * ior) * (1.0f - (dn * dn));
-          if (k < 0) {
-            const f3 rd = dir - 2.0f * (dot(normal, dir)) * normal;
-            set_ray(S, mkray(p + normal * EPSILON, rd, ib - 1));
-            S.state = ST_REFR_FINAL;
-            micro = (S.bounce == 0) ? M_POP : M_TRACE;
-          } else {
-            const f3 rd = ior * dir - (ior * (dot(normal, dir)) + sqrtf(k)) * normal;
-            set_ray(S, mkray(p - normal * 0.0001f, rd, ib));
-            S.refr_bounce = ib;
-            S.state = ST_REFR_INSIDE;
-            micro = M_TRACE;   // ib > 0 is guaranteed by the push condition
-          }
-        }
-      }
-    }
-  }
-  if (micro == M_DONE) {
-    a.samples[S.g] = make_float4(S.L.x, S.L.y, S.L.z, S.alpha);
-    S.g = -1;
-    S.trav = false;
-  } else if (micro == M_BATCH) {
-    batch_next<COUNT>(a, S, cn);
-  } else {
-    S.shadow = false;
-    S.limit = INFINITY;
-    start_ray<COUNT>(a, S, cn);
-  }
-}
-
-// Start sample `idx` on this lane: pixel, RNG stream, jitter, primary ray (draw.cu:105-123 / 162-171).
-template <bool COUNT>
-MIRT_DEV void init_sample(const RenderArgs& a, Lane& S, Counters& cn, const long long idx)
-{
-  const int sppe = a.spp > 1 ? a.spp : 1;
-  const long long stripe_pixels = (long long)a.stripe_rows * a.width;
-  const long long lp = idx / sppe;
-  const int sidx = (int)(idx - lp * sppe);
-  const long long ls = lp / stripe_pixels;
-  const long long within = lp - ls * stripe_pixels;
-  const long long gs = ls * a.num_parts + a.part;
-  const int py = (int)(gs * a.stripe_rows + within / a.width);
-  const int px = (int)(within % a.width);
-  const uint32_t pixel = (uint32_t)py * (uint32_t)a.width + (uint32_t)px;
-  S.g = idx;
-  S.L = mk3(0.0f, 0.0f, 0.0f);
-  S.alpha = 0.0f;
-  S.pc = 0;
-  S.state = ST_PRIMARY;
-  S.limit = INFINITY;
-  S.shadow = false;
-  S.batch_pending = false;
-  if (a.needs_rng) xw_init(S.rng, a.rng, pixel, (uint32_t)sidx);
-  float fx = (float)px, fy = (float)py;
-  if (a.spp >= 1) {
-    const float jx = randD(-0.5f, 0.5f, S.rng);
-    const float jy = randD(-0.5f, 0.5f, S.rng);
-    fx = (float)px + jx; fy = (float)py + jy;
-  }
-  set_ray(S, primary_ray(a, fx, fy, S.rng));
-  if (COUNT) cn.samples++;
-  if (S.bounce == 0) {   // hitNearest: a ray with bounce 0 never hits (draw.cu:294)
-    a.samples[idx] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-    S.g = -1;
-    S.trav = false;
-  } else {
-    start_ray<COUNT>(a, S, cn);
-  }
-}
-
 template <bool COUNT, bool PROF>
 __global__ void __launch_bounds__(RBLOCK, MIRT_WAVES_PER_SIMD) trace_kernel(const RenderArgs a)
 {
@@ -481,8 +52,10 @@ __global__ void __launch_bounds__(RBLOCK, MIRT_WAVES_PER_SIMD) trace_kernel(cons
   uint32_t* const lds_stack = reinterpret_cast<uint32_t*>(lds_raw);
   const int tid = threadIdx.x;
   const int lane = tid & 63;
+  (void)lane;
   unsigned char* const stage = lds_raw + STACK_LDS * RBLOCK * 4 + __builtin_amdgcn_readfirstlane(tid >> 6) * STAGE_WAVE_BYTES;
   const unsigned char* const heap = reinterpret_cast<const unsigned char*>(a.nodes);
+  (void)stage; (void)heap;
   const long long gid = (long long)blockIdx.x * RBLOCK + tid;
   const long long gthreads = (long long)gridDim.x * RBLOCK;
   Counters cn = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -940,7 +513,16 @@ int render(MirtScene* sc, const MirtRenderParams* p, void* d_rgba8, void* d_rgba
   if (count) MIRT_HIP(hipMemsetAsync(sc->counters, 0, 8 * sizeof(unsigned long long), stream));
   MIRT_HIP(hipEventRecord(sc->ev1, stream));
   const bool prof = getenv("MIRT_PROF") != nullptr;
-  if (prof) {
+  const char* wfe = getenv("MIRT_WAVEFRONT");
+  const bool wavefront = wfe ? atoi(wfe) != 0 : MIRT_DEFAULT_WAVEFRONT;
+  sc->wf_trace_ms = -1.0f;
+  if (wavefront) {
+    if (const char* e = getenv("MIRT_WF_REFILL_K")) { int k = atoi(e); if (k >= 1 && k <= 64) a.refill_k = k; } else a.refill_k = 16;
+    float tms = 0.0f;
+    int rc = wavefront_trace(sc, a, count, stream, &tms);
+    if (rc != MIRT_OK) return rc;
+    sc->wf_trace_ms = tms;
+  } else if (prof) {
     if (!sc->prof) MIRT_HIP(hipMalloc(&sc->prof, 16 * sizeof(unsigned long long)));
     MIRT_HIP(hipMemsetAsync(sc->prof, 0, 16 * sizeof(unsigned long long), stream));
     a.prof = sc->prof;

@@ -111,6 +111,14 @@ struct MirtScene {
   float* pending = nullptr; size_t pending_cap = 0;
   unsigned long long* counters = nullptr;  // 8 x u64 on device
   unsigned long long* prof = nullptr;      // diagnostic stamps (MIRT_PROF)
+  // wavefront path workspace (wavefront.hip)
+  uint32_t* wf_state = nullptr; size_t wf_state_cap = 0;
+  float4* wf_rays = nullptr; size_t wf_rays_cap = 0;
+  unsigned long long* wf_ctr = nullptr;
+  unsigned long long* wf_ctr_host = nullptr;
+  std::vector<hipEvent_t> wf_events;
+  int wf_rounds = 0;
+  float wf_trace_ms = -1.0f;            // >= 0: the last render used the wavefront path; summed trace-kernel time
   // rng tables cache
   mirt::RngCache rng;
   // timing
@@ -135,6 +143,8 @@ int probe_math(int device, int which, int n, const float* in, float* out);
 int probe_xorwow(int device, int spp, int nstreams, int draws, uint32_t* out);
 int ensure_rng_tables(RngCache* rc, int spp, long long frame_pixels, hipStream_t stream, RngTablesDev* out);
 void rng_cache_free(RngCache* rc);
+// wavefront.hip
+int wavefront_trace(MirtScene* sc, RenderArgs& a, bool count, hipStream_t stream, float* trace_ms);
 }
 #define MIRT_HIP(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) return mirt::hip_fail(e_, #call, __FILE__, __LINE__); } while (0)
 

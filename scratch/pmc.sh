@@ -17,8 +17,12 @@ out = sys.argv[1]
 for f in sorted(glob.glob(out + "/g*/*/*counter_collection.csv")):
     agg = collections.defaultdict(list)
     for r in csv.DictReader(open(f)):
-        if "trace_kernel" in r["Kernel_Name"] and "ILb1" not in r["Kernel_Name"] and "<true" not in r["Kernel_Name"]:
+        if ("trace_kernel" in r["Kernel_Name"] or "shade_kernel" in r["Kernel_Name"]) and "<true" not in r["Kernel_Name"]:
+            kn = "shade" if "shade" in r["Kernel_Name"] else "trace"
+            agg[kn + ":" + r["Counter_Name"]].append(float(r["Counter_Value"]))
+            continue
+        if False:
             agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
     for k, v in agg.items():
-        print(f"{k:45s} n={len(v)} mean={sum(v)/len(v):.5g}")
+        print(f"{k:52s} n={len(v)} sum={sum(v):.5g} mean={sum(v)/len(v):.5g}")
 PY

@@ -168,3 +168,20 @@ class OracleScene:
         rc = lib().orc_render_subsample(self.h, width, height, spp, step, C.byref(st), flags, nthreads, C.byref(cs))
         assert rc == 0
         return st.as_dict(), float(cs.value)
+
+
+class ArrayScene:
+    """Adapter: builds an oracle scene from a product StlConfig (arrays + scalars), e.g. the synthetic scene, so that
+    the oracle sees exactly the bytes the product uploaded."""
+
+    def __init__(self, stl):
+        self.width, self.height, self.bounces, self.aa = stl.width, stl.height, stl.bounces, stl.aa
+        self.dof_focus, self.dof_lens, self.expose = stl.dof_focus, stl.dof_lens, stl.expose
+        self.fisheye, self.panorama, self.gi = bool(stl.fisheye), bool(stl.panorama), stl.gi
+        d = stl.desc
+        self.forward, self.right, self.up, self.eye = d.forward.tolist(), d.right.tolist(), d.up.tolist(), d.eye.tolist()
+        self._arrays = dict(spheres=stl.array("spheres"), triangles=stl.array("triangles"), refs=stl.array("prim_refs"),
+                            planes=stl.array("planes"), suns=stl.array("suns"), bulbs=stl.array("bulbs"))
+
+    def arrays(self):
+        return self._arrays

@@ -135,3 +135,53 @@ def test_stripe_partition_is_bit_identical_to_whole_frame(gpu_scenes):
             m.scatter_part(p, buf, frame)
         torch.cuda.synchronize()
         assert np.array_equal(frame.cpu().numpy().reshape(-1, 4), whole_u8), (parts, rows)
+
+
+@pytest.mark.parametrize("ns,nt", [(30000, 30000), (300000, 200000)])
+def test_synthetic_scene_build_and_render_match_oracle(ns, nt):
+    """BASELINE config 5's generator at reduced size: multi-block radix sort, duplicate Morton codes, mixed primitives."""
+    stl = m.syntheticScene(ns, nt, seed=1234)
+    raw = m.initRawConfigFromStl(stl, 0)
+    m.build_lbvh_karas(raw)
+    o = ol.OracleScene(ol.ArrayScene(stl), bounds_mode=0)
+    nodes, codes, refs, bounds = raw.tree()
+    assert np.array_equal(codes, o.codes())
+    orefs = o.refs()
+    assert np.array_equal(refs["type"], orefs["type"]) and np.array_equal(refs["id"], orefs["id"])
+    on = o.nodes()
+    for f in ("left", "right"):
+        assert np.array_equal(nodes[f], on[f]), f
+    for f in ("xmin", "xmax", "ymin", "ymax", "zmin", "zmax"):
+        assert np.array_equal(nodes[f].view(np.uint32), on[f].view(np.uint32)), f
+    w, h, spp = 96, 54, 4
+    gu8, gf = gpu_render(raw, w, h, spp, counters=True)
+    st = raw.stats()
+    ref = o.render(w, h, spp, flags=ol.FLAG_ANYHIT_SHADOW, nthreads=8)
+    check_image(gu8, gf, ref)
+    for k in ("rays", "internal_visits", "sphere_tests", "tri_tests", "max_stack"):
+        assert st[k] == ref["stats"][k], k
+    raw.close()
+    o.close()
+
+
+@pytest.mark.parametrize("name,w,h,spp", [("tenthousand", 96, 54, 16), ("redchair", 64, 36, 32), ("spiral", 96, 54, 1), ("tri", 256, 256, 0)])
+def test_wavefront_path_matches_oracle(name, w, h, spp, gpu_scenes, oracle_scenes, monkeypatch):
+    """The trace/shade kernel pair (MIRT_WAVEFRONT=1) must give the same pixels and the same counters."""
+    monkeypatch.setenv("MIRT_WAVEFRONT", "1")
+    monkeypatch.setenv("MIRT_WF_POOL", "4096")      # small pool: many rounds, slots refilled many times
+    stl, raw = gpu_scenes(name)
+    gu8, gf = gpu_render(raw, w, h, spp, counters=True)
+    st = raw.stats()
+    ref = oracle_scenes(name).render(w, h, spp, flags=ol.FLAG_ANYHIT_SHADOW, nthreads=8)
+    check_image(gu8, gf, ref)
+    for k in ("samples", "rays", "shadow_rays", "internal_visits", "sphere_tests", "tri_tests", "mat_fetches", "max_stack"):
+        assert st[k] == ref["stats"][k], (k, st[k], ref["stats"][k])
+
+
+def test_both_paths_give_identical_bytes(gpu_scenes, monkeypatch):
+    stl, raw = gpu_scenes("tenthousand")
+    monkeypatch.setenv("MIRT_WAVEFRONT", "0")
+    a8, af = gpu_render(raw, 200, 120, 16)
+    monkeypatch.setenv("MIRT_WAVEFRONT", "1")
+    b8, bf = gpu_render(raw, 200, 120, 16)
+    assert np.array_equal(a8, b8) and np.array_equal(af.view(np.uint32), bf.view(np.uint32))
