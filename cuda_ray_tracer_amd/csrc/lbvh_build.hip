@@ -76,12 +76,19 @@ __global__ void __launch_bounds__(BLOCK) prim_bounds_kernel(const MirtPrimRef* _
       mn[k] = fminf(mn[k], __shfl_xor(mn[k], off));
       mx[k] = fmaxf(mx[k], __shfl_xor(mx[k], off));
     }
+  // one set of atomics per block (the six words are hot: every block of the grid hits them)
+  __shared__ float red[BLOCK / 64][6];
+  const int wv = threadIdx.x >> 6;
   if ((threadIdx.x & 63) == 0) {
 #pragma unroll
-    for (int k = 0; k < 3; ++k) {
-      atomicMin(&keys[k], f2key(mn[k]));
-      atomicMax(&keys[3 + k], f2key(mx[k]));
-    }
+    for (int k = 0; k < 3; ++k) { red[wv][k] = mn[k]; red[wv][3 + k] = mx[k]; }
+  }
+  __syncthreads();
+  if (threadIdx.x < 6) {
+    float v = red[0][threadIdx.x];
+    for (int i = 1; i < BLOCK / 64; ++i) v = (threadIdx.x < 3) ? fminf(v, red[i][threadIdx.x]) : fmaxf(v, red[i][threadIdx.x]);
+    if (threadIdx.x < 3) atomicMin(&keys[threadIdx.x], f2key(v));
+    else atomicMax(&keys[threadIdx.x], f2key(v));
   }
 }
 
@@ -137,9 +144,10 @@ template <bool SCATTER>
 __global__ void __launch_bounds__(BLOCK) radix_pass_kernel(const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in,
                                                            uint32_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out,
                                                            uint32_t* __restrict__ hist, const uint32_t* __restrict__ offsets,
-                                                           int n, int shift, int nblocks)
+                                                           const uint32_t* __restrict__ totals, int n, int shift, int nblocks)
 {
   __shared__ uint32_t wcnt[4][256];
+  __shared__ uint32_t dbase[256];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   for (int i = tid; i < 4 * 256; i += BLOCK) (&wcnt[0][0])[i] = 0;
   __syncthreads();
@@ -175,7 +183,17 @@ __global__ void __launch_bounds__(BLOCK) radix_pass_kernel(const uint32_t* __res
     hist[(size_t)tid * nblocks + blockIdx.x] = c0 + c1 + c2 + c3;
     return;
   }
-  const uint32_t off = offsets[(size_t)tid * nblocks + blockIdx.x];
+  // exclusive scan of the 256 digit totals (every block repeats it: 256 values)
+  const uint32_t mytot = totals[tid];
+  dbase[tid] = mytot;
+  __syncthreads();
+  for (int o = 1; o < 256; o <<= 1) {
+    const uint32_t v = (tid >= o) ? dbase[tid - o] : 0;
+    __syncthreads();
+    dbase[tid] += v;
+    __syncthreads();
+  }
+  const uint32_t off = (dbase[tid] - mytot) + offsets[(size_t)tid * nblocks + blockIdx.x];
   __syncthreads();
   wcnt[0][tid] = off; wcnt[1][tid] = off + c0; wcnt[2][tid] = off + c0 + c1; wcnt[3][tid] = off + c0 + c1 + c2;
   __syncthreads();
@@ -191,25 +209,28 @@ __global__ void __launch_bounds__(BLOCK) radix_pass_kernel(const uint32_t* __res
   }
 }
 
-// exclusive scan of hist[total] in place -> offsets; one workgroup of 1024 threads
-__global__ void __launch_bounds__(1024) scan_kernel(uint32_t* __restrict__ data, int total)
+// hist is [256 digits][nblocks].  Block d scans row d in place (exclusive) and writes the row total to totals[d]; the
+// scatter kernel adds the exclusive scan of the 256 totals (done per block in LDS).
+__global__ void __launch_bounds__(BLOCK) row_scan_kernel(uint32_t* __restrict__ hist, uint32_t* __restrict__ totals, int nblocks)
 {
-  __shared__ uint32_t sums[1024];
+  __shared__ uint32_t sums[BLOCK];
   const int tid = threadIdx.x;
-  const int chunk = (total + 1023) / 1024;
-  const int lo = tid * chunk, hi = min(lo + chunk, total);
+  uint32_t* row = hist + (size_t)blockIdx.x * nblocks;
+  const int chunk = (nblocks + BLOCK - 1) / BLOCK;
+  const int lo = tid * chunk, hi = min(lo + chunk, nblocks);
   uint32_t s = 0;
-  for (int i = lo; i < hi; ++i) s += data[i];
+  for (int i = lo; i < hi; ++i) s += row[i];
   sums[tid] = s;
   __syncthreads();
-  for (int off = 1; off < 1024; off <<= 1) {
-    uint32_t v = (tid >= off) ? sums[tid - off] : 0;
+  for (int off = 1; off < BLOCK; off <<= 1) {
+    const uint32_t v = (tid >= off) ? sums[tid - off] : 0;
     __syncthreads();
     sums[tid] += v;
     __syncthreads();
   }
-  uint32_t run = sums[tid] - s;   // exclusive
-  for (int i = lo; i < hi; ++i) { uint32_t v = data[i]; data[i] = run; run += v; }
+  uint32_t run = sums[tid] - s;
+  for (int i = lo; i < hi; ++i) { const uint32_t v = row[i]; row[i] = run; run += v; }
+  if (tid == BLOCK - 1) totals[blockIdx.x] = sums[tid];
 }
 
 // ---- Karras hierarchy ------------------------------------------------------------------------------
@@ -289,7 +310,7 @@ MIRT_DEV uint32_t make_ref(uint32_t node, uint32_t leaf_base, const uint32_t* __
 }
 
 // set_aabb_kernel_adapted, lbvh_builder.cu:324-387.  One thread per leaf; the second thread to arrive at a parent
-// merges the children.  The box stores are published by the acq_rel fetch_add on the arrival counter (the reference
+// merges the children.  The box stores are published before the arrival counter is bumped, see below (the reference
 // has no fence there).  The merging thread also writes the parent's packed traversal record.
 __global__ void __launch_bounds__(BLOCK) refit_pack_kernel(int n, const uint32_t* __restrict__ order, const MirtPrimRef* __restrict__ refs,
                                                            const float4* __restrict__ spheres, const float4* __restrict__ tri_verts,
@@ -303,11 +324,18 @@ __global__ void __launch_bounds__(BLOCK) refit_pack_kernel(int n, const uint32_t
   uint32_t cur = leaf_base + (uint32_t)j;
   const MirtPrimRef r = refs[order[j]];
   const Box b = prim_box(r.type, r.id, spheres, tri_verts);
+  // Hand-off protocol (MI355X guide, "sc1 stores and loads on both sides"): every box word is written with a write-through
+  // (agent-scope atomic) store and drained with s_waitcnt vmcnt(0) before the arrival counter is bumped; the second arriver
+  // learns from the value its own add returned that the sibling's box is out, and reads it with L1-bypassing loads.
+  // No cache-wide release/acquire fences: they cost microseconds per tree level.
   float* bp = boxes + 6 * (size_t)cur;
-  bp[0] = b.xmin; bp[1] = b.xmax; bp[2] = b.ymin; bp[3] = b.ymax; bp[4] = b.zmin; bp[5] = b.zmax;
+  __hip_atomic_store(bp + 0, b.xmin, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); __hip_atomic_store(bp + 1, b.xmax, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __hip_atomic_store(bp + 2, b.ymin, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); __hip_atomic_store(bp + 3, b.ymax, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __hip_atomic_store(bp + 4, b.zmin, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); __hip_atomic_store(bp + 5, b.zmax, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   int p = parent[cur];
   while (p != -1 && p < n - 1) {
-    const uint32_t prev = __hip_atomic_fetch_add(&arrived[p], 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const uint32_t prev = __hip_atomic_fetch_add(&arrived[p], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (prev == 0) break;
     const uint32_t lc = child_l[p], rc = child_r[p];
     const float* a = boxes + 6 * (size_t)lc;
@@ -326,9 +354,9 @@ __global__ void __launch_bounds__(BLOCK) refit_pack_kernel(int n, const uint32_t
     rec[3] = make_float4(__uint_as_float(make_ref(lc, leaf_base, order, refs)), __uint_as_float(make_ref(rc, leaf_base, order, refs)), 0.0f, 0.0f);
     // AABB(AABB, AABB), interval.cuh:83-88
     float* pb = boxes + 6 * (size_t)p;
-    pb[0] = fminf(a0, c0); pb[1] = fmaxf(a1, c1);
-    pb[2] = fminf(a2, c2); pb[3] = fmaxf(a3, c3);
-    pb[4] = fminf(a4, c4); pb[5] = fmaxf(a5, c5);
+    __hip_atomic_store(pb + 0, fminf(a0, c0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); __hip_atomic_store(pb + 1, fmaxf(a1, c1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(pb + 2, fminf(a2, c2), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); __hip_atomic_store(pb + 3, fmaxf(a3, c3), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(pb + 4, fminf(a4, c4), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); __hip_atomic_store(pb + 5, fmaxf(a5, c5), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     cur = (uint32_t)p;
     p = parent[cur];
   }
@@ -348,22 +376,23 @@ int build_lbvh(MirtScene* sc, hipStream_t stream)
   static const uint32_t init_keys[6] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0u, 0u, 0u};
   MIRT_HIP(hipMemcpyAsync(sc->bounds_keys, init_keys, sizeof(init_keys), hipMemcpyHostToDevice, stream));
   const int nblk = (n + BLOCK - 1) / BLOCK;
-  const int bgrid = nblk < 2048 ? nblk : 2048;
+  const int bgrid = nblk < 512 ? nblk : 512;
   hipLaunchKernelGGL(prim_bounds_kernel, dim3(bgrid), dim3(BLOCK), 0, stream, sc->refs_in, sc->spheres, sc->tri_verts, n, sc->bounds_keys);
 
   // morton codes + stable sort
-  uint32_t *k0 = nullptr, *v0 = nullptr, *k1 = nullptr, *v1 = nullptr, *hist = nullptr;
+  uint32_t *k0 = nullptr, *v0 = nullptr, *k1 = nullptr, *v1 = nullptr, *hist = nullptr, *totals = nullptr;
   const int sblocks = (n + SORT_TILE - 1) / SORT_TILE;
   MIRT_HIP(hipMalloc(&k0, sizeof(uint32_t) * n)); MIRT_HIP(hipMalloc(&v0, sizeof(uint32_t) * n));
   MIRT_HIP(hipMalloc(&k1, sizeof(uint32_t) * n)); MIRT_HIP(hipMalloc(&v1, sizeof(uint32_t) * n));
   MIRT_HIP(hipMalloc(&hist, sizeof(uint32_t) * 256 * (size_t)sblocks));
+  MIRT_HIP(hipMalloc(&totals, sizeof(uint32_t) * 256));
   hipLaunchKernelGGL(morton_kernel, dim3(nblk), dim3(BLOCK), 0, stream, sc->refs_in, sc->spheres, sc->tri_verts, n, sc->bounds_keys, k0, v0);
   uint32_t *ki = k0, *vi = v0, *ko = k1, *vo = v1;
   for (int pass = 0; pass < 4; ++pass) {
     const int shift = pass * 8;
-    hipLaunchKernelGGL(radix_pass_kernel<false>, dim3(sblocks), dim3(BLOCK), 0, stream, ki, vi, ko, vo, hist, hist, n, shift, sblocks);
-    hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(1024), 0, stream, hist, 256 * sblocks);
-    hipLaunchKernelGGL(radix_pass_kernel<true>, dim3(sblocks), dim3(BLOCK), 0, stream, ki, vi, ko, vo, hist, hist, n, shift, sblocks);
+    hipLaunchKernelGGL(radix_pass_kernel<false>, dim3(sblocks), dim3(BLOCK), 0, stream, ki, vi, ko, vo, hist, hist, totals, n, shift, sblocks);
+    hipLaunchKernelGGL(row_scan_kernel, dim3(256), dim3(BLOCK), 0, stream, hist, totals, sblocks);
+    hipLaunchKernelGGL(radix_pass_kernel<true>, dim3(sblocks), dim3(BLOCK), 0, stream, ki, vi, ko, vo, hist, hist, totals, n, shift, sblocks);
     uint32_t* t = ki; ki = ko; ko = t; t = vi; vi = vo; vo = t;
   }
   // after 4 passes the result is back in k0/v0
@@ -396,7 +425,7 @@ int build_lbvh(MirtScene* sc, hipStream_t stream)
   } else {
     sc->root_ref = 0;
   }
-  (void)hipFree(k0); (void)hipFree(v0); (void)hipFree(k1); (void)hipFree(v1); (void)hipFree(hist); (void)hipFree(arrived);
+  (void)hipFree(k0); (void)hipFree(v0); (void)hipFree(k1); (void)hipFree(v1); (void)hipFree(hist); (void)hipFree(totals); (void)hipFree(arrived);
   sc->built = true;
   return MIRT_OK;
 }

@@ -185,3 +185,25 @@ def test_both_paths_give_identical_bytes(gpu_scenes, monkeypatch):
     monkeypatch.setenv("MIRT_WAVEFRONT", "1")
     b8, bf = gpu_render(raw, 200, 120, 16)
     assert np.array_equal(a8, b8) and np.array_equal(af.view(np.uint32), bf.view(np.uint32))
+
+
+def test_two_million_primitive_build_matches_oracle():
+    """BASELINE config 5's scene at full size (1 M spheres + 1 M triangles): the whole tree, bit for bit.  Also the
+    regression test of the refit's fence-free hand-off (write-through stores + drained counter add)."""
+    stl = m.syntheticScene(1_000_000, 1_000_000, seed=1234)
+    raw = m.initRawConfigFromStl(stl, 0)
+    for _ in range(3):                       # rebuild a few times: the hand-off must hold under different timings
+        m.build_lbvh_karas(raw)
+    o = ol.OracleScene(ol.ArrayScene(stl), bounds_mode=0)
+    nodes, codes, refs, bounds = raw.tree()
+    assert np.array_equal(codes, o.codes())
+    on = o.nodes()
+    for f in ("left", "right"):
+        assert np.array_equal(nodes[f], on[f]), f
+    for f in ("xmin", "xmax", "ymin", "ymax", "zmin", "zmax"):
+        assert np.array_equal(nodes[f].view(np.uint32), on[f].view(np.uint32)), f
+    gu8, gf = gpu_render(raw, 64, 36, 1, counters=True)
+    ref = o.render(64, 36, 1, flags=ol.FLAG_ANYHIT_SHADOW, nthreads=8)
+    check_image(gu8, gf, ref)
+    raw.close()
+    o.close()
