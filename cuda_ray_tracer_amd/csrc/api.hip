@@ -124,12 +124,16 @@ int mirt_scene_create(const MirtSceneDesc* d, int device, MirtScene** out)
     if (N > 1) { alloc((void**)&sc->child_l, 4 * (size_t)(N - 1)); alloc((void**)&sc->child_r, 4 * (size_t)(N - 1)); }
   }
   alloc((void**)&sc->bounds_keys, 6 * 4);
-  alloc((void**)&sc->counters, 8 * sizeof(unsigned long long));
+  for (int i = 0; i < mirt::MIRT_MAX_FRAMES; ++i) alloc((void**)&sc->ctx[i].counters, 16 * sizeof(unsigned long long));
   if (rc == MIRT_OK) {
     hipError_t e = hipEventCreate(&sc->ev0);
     if (e == hipSuccess) e = hipEventCreate(&sc->ev1);
-    if (e == hipSuccess) e = hipEventCreate(&sc->ev2);
-    if (e == hipSuccess) e = hipEventCreate(&sc->ev3);
+    for (int i = 0; i < mirt::MIRT_MAX_FRAMES && e == hipSuccess; ++i) {
+      e = hipEventCreate(&sc->ctx[i].ev0);
+      if (e == hipSuccess) e = hipEventCreate(&sc->ctx[i].ev1);
+      if (e == hipSuccess) e = hipEventCreate(&sc->ctx[i].ev2);
+      if (e == hipSuccess) e = hipEventCreate(&sc->ctx[i].ev3);
+    }
     if (e != hipSuccess) rc = hip_fail(e, "hipEventCreate", __FILE__, __LINE__);
   }
   if (rc != MIRT_OK) { mirt_scene_destroy(sc); return rc; }
@@ -145,15 +149,22 @@ void mirt_scene_destroy(MirtScene* sc)
   hipFree(sc->heap); hipFree(sc->tri_verts); hipFree(sc->mats); hipFree(sc->refs_in);
   hipFree(sc->planes); hipFree(sc->suns); hipFree(sc->bulbs);
   hipFree(sc->codes); hipFree(sc->order); hipFree(sc->child_l); hipFree(sc->child_r); hipFree(sc->parent); hipFree(sc->boxes);
-  hipFree(sc->bounds_keys); hipFree(sc->samples); hipFree(sc->stack_spill); hipFree(sc->pending); hipFree(sc->counters); hipFree(sc->prof);
+  hipFree(sc->bounds_keys);
+  for (int i = 0; i < mirt::MIRT_MAX_FRAMES; ++i) {
+    mirt::RenderCtx& c = sc->ctx[i];
+    hipFree(c.samples); hipFree(c.stack_spill); hipFree(c.pending); hipFree(c.counters); hipFree(c.prof);
+    hipFree(c.chunk_cost); hipFree(c.order_out[0]); hipFree(c.order_out[1]); hipFree(c.sort_bins);
+    if (c.ev0) hipEventDestroy(c.ev0);
+    if (c.ev1) hipEventDestroy(c.ev1);
+    if (c.ev2) hipEventDestroy(c.ev2);
+    if (c.ev3) hipEventDestroy(c.ev3);
+  }
   rng_cache_free(&sc->rng);
   hipFree(sc->wf_state); hipFree(sc->wf_rays); hipFree(sc->wf_ctr);
   if (sc->wf_ctr_host) hipHostFree(sc->wf_ctr_host);
   for (hipEvent_t e : sc->wf_events) hipEventDestroy(e);
   if (sc->ev0) hipEventDestroy(sc->ev0);
   if (sc->ev1) hipEventDestroy(sc->ev1);
-  if (sc->ev2) hipEventDestroy(sc->ev2);
-  if (sc->ev3) hipEventDestroy(sc->ev3);
   delete sc;
 }
 
@@ -188,14 +199,26 @@ int mirt_get_stats(MirtScene* sc, MirtStats* out)
   MIRT_HIP(hipSetDevice(sc->device));
   out->build_ms = sc->build_ms;
   out->num_nodes = sc->N > 0 ? 2 * sc->N - 1 : 0;
-  if (!sc->have_render) return MIRT_OK;
-  MIRT_HIP(hipEventSynchronize(sc->ev3));
-  MIRT_HIP(hipEventElapsedTime(&out->trace_kernel_ms, sc->ev1, sc->ev2));
-  if (sc->wf_trace_ms >= 0.0f) out->trace_kernel_ms = sc->wf_trace_ms;
-  MIRT_HIP(hipEventElapsedTime(&out->render_ms, sc->ev0, sc->ev3));
-  if (sc->last_counted) {
+  if (!sc->last) return MIRT_OK;
+  for (int i = 0; i < mirt::MIRT_MAX_FRAMES; ++i) {   // finish and time every frame still in flight
+    mirt::RenderCtx& c = sc->ctx[i];
+    if (c.used && !c.timed) {
+      MIRT_HIP(hipEventSynchronize(c.ev3));
+      float ms = 0.0f;
+      MIRT_HIP(hipEventElapsedTime(&ms, c.ev1, c.ev2));
+      sc->trace_ms_sum += (c.wf_trace_ms >= 0.0f) ? c.wf_trace_ms : ms; sc->trace_frames += 1; c.timed = true;
+    }
+  }
+  out->frames_timed = sc->trace_frames;
+  out->trace_kernel_ms_mean = sc->trace_frames ? (float)(sc->trace_ms_sum / sc->trace_frames) : 0.0f;
+  sc->trace_ms_sum = 0.0; sc->trace_frames = 0;
+  mirt::RenderCtx& cx = *sc->last;
+  MIRT_HIP(hipEventElapsedTime(&out->trace_kernel_ms, cx.ev1, cx.ev2));
+  if (cx.wf_trace_ms >= 0.0f) out->trace_kernel_ms = cx.wf_trace_ms;
+  MIRT_HIP(hipEventElapsedTime(&out->render_ms, cx.ev0, cx.ev3));
+  if (cx.counted) {
     unsigned long long c[8];
-    MIRT_HIP(hipMemcpy(c, sc->counters, sizeof(c), hipMemcpyDeviceToHost));
+    MIRT_HIP(hipMemcpy(c, cx.counters, sizeof(c), hipMemcpyDeviceToHost));
     out->samples = c[0]; out->rays = c[1]; out->shadow_rays = c[2]; out->internal_visits = c[3];
     out->sphere_tests = c[4]; out->tri_tests = c[5]; out->mat_fetches = c[6]; out->max_stack = c[7];
   }

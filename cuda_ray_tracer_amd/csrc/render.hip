@@ -26,6 +26,8 @@ namespace mirt {
 namespace {
 
 constexpr int RBLOCK = 256;
+constexpr int WORK_CHUNK = 256;       // samples a wave takes from the frame per atomic (shade_common.h assumes 256: g >> 8)
+constexpr int DRAIN_LANES = 16;       // a wave with this few live lanes (and no work left to fetch) stops batching
 #ifndef MIRT_DEFAULT_WAVEFRONT
 #define MIRT_DEFAULT_WAVEFRONT 0
 #endif
@@ -60,19 +62,17 @@ __global__ void __launch_bounds__(RBLOCK, MIRT_WAVES_PER_SIMD) trace_kernel(cons
   const long long gthreads = (long long)gridDim.x * RBLOCK;
   Counters cn = {0, 0, 0, 0, 0, 0, 0, 0};
 
-  // Work distribution without atomics: the sample range is cut into blocks of 64 consecutive samples (4 pixels at
-  // 16 spp); wave w owns blocks w, w + nwaves, w + 2 nwaves, ... and its lanes draw samples from them in order.
-  const long long nwaves = gthreads / 64;
-  const long long wave_id = gid / 64;
-  const long long nblocks64 = (a.num_samples + 63) / 64;
-  const long long my_blocks = (nblocks64 > wave_id) ? (nblocks64 - 1 - wave_id) / nwaves + 1 : 0;
-  const long long my_total = my_blocks * 64;
-  long long consumed = 0;       // wave-uniform
+  // Work distribution: the sample range is cut into chunks of WORK_CHUNK consecutive samples (16 pixels at 16 spp); a wave
+  // takes the next chunk from a global counter whenever its local one is used up (one atomic per chunk), so waves that
+  // draw cheap samples simply draw more of them -- this is what keeps the tail short when a GPU renders only a stripe set.
+  unsigned long long c_next = 0, c_end = 0;   // wave-uniform: this wave's current chunk
+  const unsigned long long nchunks = ((unsigned long long)a.num_samples + WORK_CHUNK - 1) / WORK_CHUNK;
+  bool exhausted = false;                      // wave-uniform: the global counter has run past the frame
 
   Lane S;
   S.g = -1; S.trav = false;
   S.rng.v0 = S.rng.v1 = S.rng.v2 = S.rng.v3 = S.rng.v4 = S.rng.d = 0; S.rng.bm_flag = 0; S.rng.bm_extra = 0.0f;
-  S.L = mk3(0, 0, 0); S.alpha = 0.0f;
+  S.L = mk3(0, 0, 0); S.alpha = 0.0f; S.steps = 0;
   S.Hdir = mk3(0, 0, 0); S.Hp = mk3(0, 0, 0); S.Hn = mk3(0, 0, 0); S.Hcolor = mk3(0, 0, 0);
   S.Hbounce = 0; S.Hior = 1.458f; S.Hrough = 0.0f; S.HtransNZ = false;
   S.wt = mk3(1, 1, 1); S.wD = mk3(0, 0, 0); S.pn = mk3(0, 0, 0);
@@ -90,20 +90,37 @@ __global__ void __launch_bounds__(RBLOCK, MIRT_WAVES_PER_SIMD) trace_kernel(cons
       if (S.batch_pending) batch_next<COUNT>(a, S, cn);
       else advance<COUNT>(a, S, cn, gid, gthreads);
     }
-    if (consumed < my_total) {
+    if (!exhausted) {
       const unsigned long long need = __ballot(!S.trav && S.g < 0);
       if (need) {
+        const int want = __popcll(need);
         const int r = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(need >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)need, 0u));
-        const long long k = consumed + r;
-        consumed += __popcll(need);
-        if (!S.trav && S.g < 0 && k < my_total) {
-          const long long idx = ((k >> 6) * nwaves + wave_id) * 64 + (k & 63);
-          if (idx < a.num_samples) init_sample<COUNT>(a, S, cn, idx);
+        int given = 0;
+        long long my = -1;
+        while (given < want) {
+          if (c_next >= c_end) {
+            unsigned long long k = 0;
+            if (lane == 0) {
+              k = atomicAdd(a.work_counter, 1ull);
+              // longest-first hand-out order measured on an earlier frame (any order gives the same pixels)
+              if (k < nchunks && a.chunk_order) k = a.chunk_order[k];
+            }
+            k = __shfl(k, 0);
+            if (k >= nchunks) { exhausted = true; break; }
+            c_next = k * WORK_CHUNK;
+            c_end = (c_next + WORK_CHUNK < (unsigned long long)a.num_samples) ? c_next + WORK_CHUNK : (unsigned long long)a.num_samples;
+          }
+          const int avail = (int)(c_end - c_next);
+          const int take = (want - given < avail) ? want - given : avail;
+          if (!S.trav && S.g < 0 && r >= given && r < given + take) my = (long long)c_next + (r - given);
+          c_next += (unsigned long long)take;
+          given += take;
         }
+        if (my >= 0) init_sample<COUNT>(a, S, cn, my);
       }
     }
     if (__ballot(S.trav) == 0) {
-      if (consumed >= my_total && __ballot(S.g >= 0) == 0) break;
+      if (exhausted && __ballot(S.g >= 0) == 0) break;
       continue;
     }
 
@@ -115,10 +132,16 @@ __global__ void __launch_bounds__(RBLOCK, MIRT_WAVES_PER_SIMD) trace_kernel(cons
       const unsigned long long tm = __ballot(S.trav);
       const unsigned long long bm = __ballot(!S.trav && S.batch_pending);
       if (tm == 0 && bm == 0) break;
-      // leave when enough lanes are waiting to shade (they cannot progress while the wave keeps traversing)
-      if (__popcll(__ballot(!S.trav && !S.batch_pending && S.g >= 0)) >= a.refill_k) break;
+      // leave when enough lanes are waiting to shade (they cannot progress while the wave keeps traversing); a wave with
+      // few live lanes (the drain at the end of the frame) does not wait for company: there the critical path is one
+      // lane's bounce chain
+      // lanes that wait: to shade, or (finished) for a new sample while the frame still has some
+      const int nwait = __popcll(__ballot(!S.trav && !S.batch_pending && (S.g >= 0 || !exhausted)));
+      const int nlive = __popcll(__ballot(S.g >= 0));
+      const bool drain = exhausted && nlive <= DRAIN_LANES;
+      if (nwait >= a.refill_k || (drain && nwait > 0)) break;
       // lanes whose batch ray finished move on to the next ray of their batch (cheap; done in groups)
-      if (bm != 0 && (__popcll(bm) >= a.batch_k || tm == 0)) {
+      if (bm != 0 && (__popcll(bm) >= a.batch_k || tm == 0 || drain)) {
         if (PROF) { pf_Bent++; pf_Blanes += __popcll(bm); }
         if (!S.trav && S.batch_pending) batch_next<COUNT>(a, S, cn);
       }
@@ -147,6 +170,7 @@ __global__ void __launch_bounds__(RBLOCK, MIRT_WAVES_PER_SIMD) trace_kernel(cons
       }
 #endif
       if (S.trav) {
+        ++S.steps;
         // one fetch per iteration: the record `cur` names -- a node (4 x 16 B) or a primitive (sphere 16 B, triangle 48 B)
         const bool leaf = (S.cur & REF_LEAF) != 0;
         const bool tri = leaf && (S.cur & REF_TRI);
@@ -383,6 +407,36 @@ __global__ void probe_xorwow_kernel(RngTablesDev t, int spp, int nstreams, int d
   for (int k = 0; k < draws; ++k) out[(size_t)i * draws + k] = xw_next(s);
 }
 
+// ---- longest-first scheduling: order the frame's chunks by the cost measured on a previous frame ------------------------
+constexpr int SORT_BINS = 1024;
+MIRT_DEV uint32_t cost_bin(uint32_t c) { const uint32_t b = c >> 3; return b < (uint32_t)SORT_BINS ? (uint32_t)(SORT_BINS - 1) - b : 0u; }   // bin 0 = most expensive
+__global__ void __launch_bounds__(RBLOCK) order_hist_kernel(const uint32_t* __restrict__ cost, uint32_t n, uint32_t* __restrict__ bins)
+{
+  const uint32_t i = blockIdx.x * RBLOCK + threadIdx.x;
+  if (i < n) atomicAdd(&bins[cost_bin(cost[i])], 1u);
+}
+__global__ void __launch_bounds__(SORT_BINS) order_scan_kernel(uint32_t* __restrict__ bins)
+{
+  __shared__ uint32_t s[SORT_BINS];
+  const int t = threadIdx.x;
+  const uint32_t v = bins[t];
+  s[t] = v;
+  __syncthreads();
+  for (int o = 1; o < SORT_BINS; o <<= 1) {
+    const uint32_t x = (t >= o) ? s[t - o] : 0;
+    __syncthreads();
+    s[t] += x;
+    __syncthreads();
+  }
+  bins[t] = s[t] - v;
+}
+__global__ void __launch_bounds__(RBLOCK) order_scatter_kernel(const uint32_t* __restrict__ cost, uint32_t n, uint32_t* __restrict__ bins,
+                                                               uint32_t* __restrict__ order)
+{
+  const uint32_t i = blockIdx.x * RBLOCK + threadIdx.x;
+  if (i < n) order[atomicAdd(&bins[cost_bin(cost[i])], 1u)] = i;
+}
+
 int64_t local_pixels(const MirtRenderParams* p)
 {
   if (p->width <= 0 || p->height <= 0 || p->stripe_rows <= 0 || p->num_parts <= 0 || p->part < 0 || p->part >= p->num_parts) return -1;
@@ -404,7 +458,7 @@ int ensure_rng_tables(RngCache* rc, int spp, long long frame_pixels, hipStream_t
   if (rc->key != key) {
     if (spp > 1) build_sample_tables(spp, rc->host);
     else build_pixel_tables(frame_pixels, 1234, rc->host);
-    MIRT_HIP(hipStreamSynchronize(stream));
+    MIRT_HIP(hipDeviceSynchronize());   // another stream may still be reading the old tables
     rng_cache_free(rc);
     const RngTables& t = rc->host;
     MIRT_HIP(hipMalloc(&rc->A, t.A.size() * 4)); MIRT_HIP(hipMemcpy(rc->A, t.A.data(), t.A.size() * 4, hipMemcpyHostToDevice));
@@ -451,28 +505,39 @@ int render(MirtScene* sc, const MirtRenderParams* p, void* d_rgba8, void* d_rgba
   const int blocks = (int)(want_blocks < blocks_cached ? want_blocks : blocks_cached);
   const size_t gthreads = (size_t)blocks * RBLOCK;
 
+  // this frame's context; wait for the frame that used it MIRT_MAX_FRAMES renders ago
+  RenderCtx& cx = sc->ctx[sc->frame_no % MIRT_MAX_FRAMES];
+  ++sc->frame_no;
+  if (cx.used) {
+    MIRT_HIP(hipEventSynchronize(cx.ev3));
+    if (!cx.timed) {   // fold the finished frame's trace-kernel time into the running mean (mirt_get_stats)
+      float ms = 0.0f;
+      MIRT_HIP(hipEventElapsedTime(&ms, cx.ev1, cx.ev2));
+      sc->trace_ms_sum += (cx.wf_trace_ms >= 0.0f) ? cx.wf_trace_ms : ms; sc->trace_frames += 1; cx.timed = true;
+    }
+  }
   // workspace
-  if (sc->samples_cap < (size_t)nsamples) {
+  if (cx.samples_cap < (size_t)nsamples) {
     MIRT_HIP(hipStreamSynchronize(stream));
-    hipFree(sc->samples); sc->samples = nullptr; sc->samples_cap = 0;
-    MIRT_HIP(hipMalloc(&sc->samples, sizeof(float4) * (size_t)nsamples));
-    sc->samples_cap = (size_t)nsamples;
+    hipFree(cx.samples); cx.samples = nullptr; cx.samples_cap = 0;
+    MIRT_HIP(hipMalloc(&cx.samples, sizeof(float4) * (size_t)nsamples));
+    cx.samples_cap = (size_t)nsamples;
   }
   const size_t spill_need = (size_t)STACK_TOTAL * gthreads;
-  if (sc->spill_cap < spill_need) {
+  if (cx.spill_cap < spill_need) {
     MIRT_HIP(hipStreamSynchronize(stream));
-    hipFree(sc->stack_spill); sc->stack_spill = nullptr; sc->spill_cap = 0;
-    MIRT_HIP(hipMalloc(&sc->stack_spill, sizeof(uint32_t) * spill_need));
-    sc->spill_cap = spill_need;
+    hipFree(cx.stack_spill); cx.stack_spill = nullptr; cx.spill_cap = 0;
+    MIRT_HIP(hipMalloc(&cx.stack_spill, sizeof(uint32_t) * spill_need));
+    cx.spill_cap = spill_need;
   }
   const bool need_pending = sc->any_trans || sc->d.gi != 0;
   const int pending_slots = need_pending ? 2 * (sc->d.bounces + (sc->d.gi > 0 ? sc->d.gi : 0) + 2) : 0;
   const size_t pending_need = (size_t)pending_slots * PENDING_WORDS * gthreads;
-  if (sc->pending_cap < pending_need) {
+  if (cx.pending_cap < pending_need) {
     MIRT_HIP(hipStreamSynchronize(stream));
-    hipFree(sc->pending); sc->pending = nullptr; sc->pending_cap = 0;
-    MIRT_HIP(hipMalloc(&sc->pending, sizeof(float) * pending_need));
-    sc->pending_cap = pending_need;
+    hipFree(cx.pending); cx.pending = nullptr; cx.pending_cap = 0;
+    MIRT_HIP(hipMalloc(&cx.pending, sizeof(float) * pending_need));
+    cx.pending_cap = pending_need;
   }
 
   RenderArgs a;
@@ -498,10 +563,10 @@ int render(MirtScene* sc, const MirtRenderParams* p, void* d_rgba8, void* d_rgba
     int rc = ensure_rng_tables(&sc->rng, p->spp, (long long)p->width * p->height, stream, &a.rng);
     if (rc != MIRT_OK) return rc;
   }
-  a.samples = sc->samples;
-  a.stack_spill = sc->stack_spill;
-  a.pending = sc->pending; a.pending_slots = pending_slots;
-  a.counters = count ? sc->counters : nullptr;
+  a.samples = cx.samples;
+  a.stack_spill = cx.stack_spill;
+  a.pending = cx.pending; a.pending_slots = pending_slots;
+  a.counters = count ? cx.counters : nullptr;
   a.lds_depth = STACK_LDS;
   if (const char* e = getenv("MIRT_STACK_LDS_DEPTH")) { int k = atoi(e); if (k >= 0 && k <= STACK_LDS) a.lds_depth = k; }   // tests: force the spill path
   a.refill_k = 32;
@@ -509,42 +574,89 @@ int render(MirtScene* sc, const MirtRenderParams* p, void* d_rgba8, void* d_rgba
   if (const char* e = getenv("MIRT_BATCH_K")) { int k = atoi(e); if (k >= 1 && k <= 64) a.batch_k = k; }
   if (const char* e = getenv("MIRT_REFILL_K")) { int k = atoi(e); if (k >= 1 && k <= 64) a.refill_k = k; }
 
-  MIRT_HIP(hipEventRecord(sc->ev0, stream));
-  if (count) MIRT_HIP(hipMemsetAsync(sc->counters, 0, 8 * sizeof(unsigned long long), stream));
-  MIRT_HIP(hipEventRecord(sc->ev1, stream));
+  // ---- longest-first chunk order (single-kernel path) ----------------------------------------------------------------
+  const size_t nchunks = (size_t)((nsamples + WORK_CHUNK - 1) / WORK_CHUNK);
+  if (cx.chunk_cap < nchunks) {
+    MIRT_HIP(hipDeviceSynchronize());   // a frame on another stream may still be reading one of these orders
+    hipFree(cx.chunk_cost); hipFree(cx.order_out[0]); hipFree(cx.order_out[1]); hipFree(cx.sort_bins);
+    cx.chunk_cost = nullptr; cx.order_out[0] = cx.order_out[1] = nullptr; cx.sort_bins = nullptr; cx.chunk_cap = 0; cx.order_key = -1;
+    MIRT_HIP(hipMalloc(&cx.chunk_cost, 4 * nchunks)); MIRT_HIP(hipMalloc(&cx.order_out[0], 4 * nchunks));
+    MIRT_HIP(hipMalloc(&cx.order_out[1], 4 * nchunks)); MIRT_HIP(hipMalloc(&cx.sort_bins, 4 * SORT_BINS));
+    cx.chunk_cap = nchunks;
+  }
+  // the newest finished frame with the same sample count provides the order; a frame that is still running does not
+  const uint32_t* order = nullptr;
+  {
+    unsigned long long best = 0;
+    for (int i = 0; i < MIRT_MAX_FRAMES; ++i) {
+      RenderCtx& c = sc->ctx[i];
+      if (&c == &cx || !c.used || c.order_key != nsamples || c.frame_id <= best) continue;
+      if (hipEventQuery(c.ev3) != hipSuccess) continue;
+      best = c.frame_id; order = c.order_out[(c.uses - 1) & 1u];
+    }
+    if (!order && cx.used && cx.order_key == nsamples) order = cx.order_out[(cx.uses - 1) & 1u];   // cx's own previous frame (finished: synchronised above)
+  }
+  static const bool sched = getenv("MIRT_NO_SCHED") == nullptr;
+  if (!sched) order = nullptr;
+  a.chunk_order = order;
+  a.chunk_cost = sched ? cx.chunk_cost : nullptr;
+  cx.frame_id = ++sc->frame_seq;
+  MIRT_HIP(hipEventRecord(cx.ev0, stream));
+  if (sched) MIRT_HIP(hipMemsetAsync(cx.chunk_cost, 0, 4 * nchunks, stream));
+  if (count) MIRT_HIP(hipMemsetAsync(cx.counters, 0, 8 * sizeof(unsigned long long), stream));
+  MIRT_HIP(hipMemsetAsync(cx.counters + 8, 0, sizeof(unsigned long long), stream));
+  a.work_counter = cx.counters + 8;
+  MIRT_HIP(hipEventRecord(cx.ev1, stream));
   const bool prof = getenv("MIRT_PROF") != nullptr;
   const char* wfe = getenv("MIRT_WAVEFRONT");
   const bool wavefront = wfe ? atoi(wfe) != 0 : MIRT_DEFAULT_WAVEFRONT;
-  sc->wf_trace_ms = -1.0f;
+  cx.wf_trace_ms = -1.0f;
   if (wavefront) {
     if (const char* e = getenv("MIRT_WF_REFILL_K")) { int k = atoi(e); if (k >= 1 && k <= 64) a.refill_k = k; } else a.refill_k = 16;
     float tms = 0.0f;
-    int rc = wavefront_trace(sc, a, count, stream, &tms);
+    int rc = wavefront_trace(sc, cx, a, count, stream, &tms);
     if (rc != MIRT_OK) return rc;
-    sc->wf_trace_ms = tms;
+    cx.wf_trace_ms = tms;
   } else if (prof) {
-    if (!sc->prof) MIRT_HIP(hipMalloc(&sc->prof, 16 * sizeof(unsigned long long)));
-    MIRT_HIP(hipMemsetAsync(sc->prof, 0, 16 * sizeof(unsigned long long), stream));
-    a.prof = sc->prof;
+    if (!cx.prof) MIRT_HIP(hipMalloc(&cx.prof, 16 * sizeof(unsigned long long)));
+    MIRT_HIP(hipMemsetAsync(cx.prof, 0, 16 * sizeof(unsigned long long), stream));
+    a.prof = cx.prof;
     hipLaunchKernelGGL((trace_kernel<false, true>), dim3(blocks), dim3(RBLOCK), 0, stream, a);
     MIRT_HIP(hipStreamSynchronize(stream));
     unsigned long long h[16];
-    MIRT_HIP(hipMemcpy(h, sc->prof, sizeof(h), hipMemcpyDeviceToHost));
+    MIRT_HIP(hipMemcpy(h, cx.prof, sizeof(h), hipMemcpyDeviceToHost));
     fprintf(stderr, "[mirt prof] waves=%llu cyc/wave=%.3g S=%.1f%% T=%.1f%% | T-iters/wave=%.0f active/iter=%.1f leaf-lanes/iter=%.1f | S-entries/wave=%.0f lanes/entry=%.1f | B-entries/wave=%.0f lanes/entry=%.1f\n",
             h[10], (double)h[0] / h[10], 100.0 * h[1] / h[0], 100.0 * h[2] / h[0], (double)h[3] / h[10], (double)h[4] / (h[3] ? h[3] : 1), (double)h[9] / (h[3] ? h[3] : 1),
             (double)h[5] / h[10], (double)h[6] / (h[5] ? h[5] : 1), (double)h[7] / h[10], (double)h[8] / (h[7] ? h[7] : 1));
   } else if (count) hipLaunchKernelGGL((trace_kernel<true, false>), dim3(blocks), dim3(RBLOCK), 0, stream, a);
   else hipLaunchKernelGGL((trace_kernel<false, false>), dim3(blocks), dim3(RBLOCK), 0, stream, a);
   MIRT_HIP(hipGetLastError());
-  MIRT_HIP(hipEventRecord(sc->ev2, stream));
+  MIRT_HIP(hipEventRecord(cx.ev2, stream));
 
   ResolveArgs ra;
-  ra.samples = sc->samples; ra.rgba8 = (unsigned char*)d_rgba8; ra.rgba_f32 = (float4*)d_rgba_f32;
+  ra.samples = cx.samples; ra.rgba8 = (unsigned char*)d_rgba8; ra.rgba_f32 = (float4*)d_rgba_f32;
   ra.num_local_pixels = npix; ra.spp = p->spp;
   hipLaunchKernelGGL(resolve_kernel, dim3((unsigned)((npix + RBLOCK - 1) / RBLOCK)), dim3(RBLOCK), 0, stream, ra);
   MIRT_HIP(hipGetLastError());
-  MIRT_HIP(hipEventRecord(sc->ev3, stream));
-  sc->last_stream = stream; sc->have_render = true; sc->last_counted = count;
+  if (sched && !wavefront) {
+    // order for later frames.  It overwrites the buffer this context produced two uses ago; frames on other streams that
+    // might still read that buffer are older than this one, so the sort waits for their trace kernels.
+    for (int i = 0; i < MIRT_MAX_FRAMES; ++i) {
+      RenderCtx& c = sc->ctx[i];
+      if (&c != &cx && c.used) MIRT_HIP(hipStreamWaitEvent(stream, c.ev2, 0));
+    }
+    uint32_t* out = cx.order_out[cx.uses & 1u];
+    MIRT_HIP(hipMemsetAsync(cx.sort_bins, 0, 4 * SORT_BINS, stream));
+    const unsigned gb = (unsigned)((nchunks + RBLOCK - 1) / RBLOCK);
+    hipLaunchKernelGGL(order_hist_kernel, dim3(gb), dim3(RBLOCK), 0, stream, cx.chunk_cost, (uint32_t)nchunks, cx.sort_bins);
+    hipLaunchKernelGGL(order_scan_kernel, dim3(1), dim3(SORT_BINS), 0, stream, cx.sort_bins);
+    hipLaunchKernelGGL(order_scatter_kernel, dim3(gb), dim3(RBLOCK), 0, stream, cx.chunk_cost, (uint32_t)nchunks, cx.sort_bins, out);
+    MIRT_HIP(hipGetLastError());
+    cx.order_key = nsamples;
+  } else cx.order_key = -1;
+  ++cx.uses;
+  MIRT_HIP(hipEventRecord(cx.ev3, stream));
+  cx.used = true; cx.counted = count; cx.timed = false; sc->last = &cx;
   return MIRT_OK;
 }
 

@@ -59,6 +59,9 @@ struct RenderArgs {
   int batch_k;                    // start the next rays of ray batches when this many lanes wait for one
   unsigned long long* counters;   // MirtStats head (8 x u64) or null
   unsigned long long* prof;       // diagnostic build only (MIRT_PROF)
+  unsigned long long* work_counter; // next unclaimed chunk of the frame (single-kernel path)
+  const uint32_t* chunk_order;      // chunk k of the hand-out order is chunk chunk_order[k] of the frame (null: identity)
+  uint32_t* chunk_cost;             // per chunk: the largest number of traversal steps one of its samples took
 };
 
 struct ResolveArgs {
@@ -74,6 +77,28 @@ struct RngCache {
   RngTables host;
   long long key = -1;
   uint4* A = nullptr; uint32_t* B = nullptr; uint32_t* K = nullptr; uint32_t* R2 = nullptr;
+};
+
+constexpr int MIRT_MAX_FRAMES = 4;
+// everything one frame in flight owns
+struct RenderCtx {
+  float4* samples = nullptr; size_t samples_cap = 0;
+  uint32_t* stack_spill = nullptr; size_t spill_cap = 0;
+  float* pending = nullptr; size_t pending_cap = 0;
+  unsigned long long* counters = nullptr;  // device: [0..7] MirtStats counters, [8] work counter
+  unsigned long long* prof = nullptr;      // diagnostic stamps (MIRT_PROF)
+  hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr, ev3 = nullptr;   // render start / trace start / trace end / render end
+  bool used = false, counted = false, timed = true;
+  // longest-first scheduling: this frame's per-chunk cost, and the hand-out orders computed from it (two buffers used in
+  // turn, so that a frame still reading an order never sees it rewritten)
+  uint32_t* chunk_cost = nullptr;
+  uint32_t* order_out[2] = {nullptr, nullptr};
+  uint32_t* sort_bins = nullptr;
+  size_t chunk_cap = 0;
+  unsigned uses = 0;
+  unsigned long long frame_id = 0;         // sequence number of the frame that last used this context
+  long long order_key = -1;                // num_samples the order in order_out[(uses - 1) & 1] was computed for
+  float wf_trace_ms = -1.0f;               // >= 0: the wavefront path ran; summed trace-kernel time
 };
 
 } // namespace mirt
@@ -105,12 +130,13 @@ struct MirtScene {
   uint32_t root_ref = mirt::REF_NONE;
   bool built = false;
   float build_ms = 0.0f;
-  // render workspace
-  float4* samples = nullptr; size_t samples_cap = 0;
-  uint32_t* stack_spill = nullptr; size_t spill_cap = 0;
-  float* pending = nullptr; size_t pending_cap = 0;
-  unsigned long long* counters = nullptr;  // 8 x u64 on device
-  unsigned long long* prof = nullptr;      // diagnostic stamps (MIRT_PROF)
+  // render workspaces: MIRT_MAX_FRAMES contexts so that several frames can be in flight on different streams (the next frame's blocks fill the
+  // CUs the draining frame frees); a context is reused only after its previous frame has finished
+  mirt::RenderCtx ctx[mirt::MIRT_MAX_FRAMES];
+  unsigned frame_no = 0;
+  unsigned long long frame_seq = 0;
+  mirt::RenderCtx* last = nullptr;        // context of the most recent render (mirt_get_stats)
+  double trace_ms_sum = 0.0; int trace_frames = 0;   // trace-kernel time of the frames finished since the last mirt_get_stats
   // wavefront path workspace (wavefront.hip)
   uint32_t* wf_state = nullptr; size_t wf_state_cap = 0;
   float4* wf_rays = nullptr; size_t wf_rays_cap = 0;
@@ -118,14 +144,10 @@ struct MirtScene {
   unsigned long long* wf_ctr_host = nullptr;
   std::vector<hipEvent_t> wf_events;
   int wf_rounds = 0;
-  float wf_trace_ms = -1.0f;            // >= 0: the last render used the wavefront path; summed trace-kernel time
   // rng tables cache
   mirt::RngCache rng;
-  // timing
-  hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr, ev3 = nullptr;
-  hipStream_t last_stream = nullptr;
-  bool have_render = false;
-  bool last_counted = false;
+  // LBVH build timing
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
   bool any_trans = false;                  // some material has transparency != 0
   bool any_rough = false;
 };
@@ -144,7 +166,7 @@ int probe_xorwow(int device, int spp, int nstreams, int draws, uint32_t* out);
 int ensure_rng_tables(RngCache* rc, int spp, long long frame_pixels, hipStream_t stream, RngTablesDev* out);
 void rng_cache_free(RngCache* rc);
 // wavefront.hip
-int wavefront_trace(MirtScene* sc, RenderArgs& a, bool count, hipStream_t stream, float* trace_ms);
+int wavefront_trace(MirtScene* sc, RenderCtx& cx, RenderArgs& a, bool count, hipStream_t stream, float* trace_ms);
 }
 #define MIRT_HIP(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) return mirt::hip_fail(e_, #call, __FILE__, __LINE__); } while (0)
 

@@ -114,6 +114,7 @@ struct Lane {
   Xorwow rng;
   f3 L;
   float alpha;
+  uint32_t steps;     // traversal steps this sample has taken so far (scheduling statistic)
   // current shading node H: the ray that produced it and the hit
   f3 Hdir, Hp, Hn, Hcolor;
   int Hbounce;
@@ -405,6 +406,7 @@ MIRT_DEV void advance(const RenderArgs& a, Lane& S, Counters& cn, const long lon
   const int micro = advance_core<COUNT>(a, S, cn, gid, gthreads);
   if (micro == M_DONE) {
     a.samples[S.g] = make_float4(S.L.x, S.L.y, S.L.z, S.alpha);
+    if (a.chunk_cost) atomicMax(&a.chunk_cost[S.g >> 8], S.steps);     // WORK_CHUNK = 256 samples
     S.g = -1;
     S.trav = false;
   } else if (micro == M_BATCH) {
@@ -431,6 +433,7 @@ MIRT_DEV void init_sample_core(const RenderArgs& a, Lane& S, Counters& cn, const
   const int px = (int)(within % a.width);
   const uint32_t pixel = (uint32_t)py * (uint32_t)a.width + (uint32_t)px;
   S.g = idx;
+  S.steps = 0;
   S.L = mk3(0.0f, 0.0f, 0.0f);
   S.alpha = 0.0f;
   S.pc = 0;

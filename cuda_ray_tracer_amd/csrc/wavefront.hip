@@ -494,7 +494,7 @@ __global__ void wf_reset_kernel(uint32_t* state, int pool)
 
 // Host side: runs shade / trace rounds until the frame's samples are all finished.
 // Returns the summed trace-kernel time (ms, HIP events) in *trace_ms.
-int wavefront_trace(MirtScene* sc, RenderArgs& a, bool count, hipStream_t stream, float* trace_ms)
+int wavefront_trace(MirtScene* sc, RenderCtx& cx, RenderArgs& a, bool count, hipStream_t stream, float* trace_ms)
 {
   const long long nsamples = a.num_samples;
   int pool = 1 << 21;
@@ -528,13 +528,13 @@ int wavefront_trace(MirtScene* sc, RenderArgs& a, bool count, hipStream_t stream
   const bool need_pending = sc->any_trans || sc->d.gi != 0;
   const int pending_slots = need_pending ? 2 * (sc->d.bounces + (sc->d.gi > 0 ? sc->d.gi : 0) + 2) : 0;
   const size_t pending_need = (size_t)pending_slots * PENDING_WORDS * pool;
-  if (sc->pending_cap < pending_need) {
+  if (cx.pending_cap < pending_need) {
     MIRT_HIP(hipStreamSynchronize(stream));
-    hipFree(sc->pending); sc->pending = nullptr; sc->pending_cap = 0;
-    MIRT_HIP(hipMalloc(&sc->pending, sizeof(float) * pending_need));
-    sc->pending_cap = pending_need;
+    hipFree(cx.pending); cx.pending = nullptr; cx.pending_cap = 0;
+    MIRT_HIP(hipMalloc(&cx.pending, sizeof(float) * pending_need));
+    cx.pending_cap = pending_need;
   }
-  a.pending = sc->pending; a.pending_slots = pending_slots;
+  a.pending = cx.pending; a.pending_slots = pending_slots;
 
   static int trace_blocks = 0;
   if (!trace_blocks) {
@@ -546,13 +546,13 @@ int wavefront_trace(MirtScene* sc, RenderArgs& a, bool count, hipStream_t stream
   }
   const size_t gthreads = (size_t)trace_blocks * WBLOCK;
   const size_t spill_need = (size_t)STACK_TOTAL * gthreads;
-  if (sc->spill_cap < spill_need) {
+  if (cx.spill_cap < spill_need) {
     MIRT_HIP(hipStreamSynchronize(stream));
-    hipFree(sc->stack_spill); sc->stack_spill = nullptr; sc->spill_cap = 0;
-    MIRT_HIP(hipMalloc(&sc->stack_spill, sizeof(uint32_t) * spill_need));
-    sc->spill_cap = spill_need;
+    hipFree(cx.stack_spill); cx.stack_spill = nullptr; cx.spill_cap = 0;
+    MIRT_HIP(hipMalloc(&cx.stack_spill, sizeof(uint32_t) * spill_need));
+    cx.spill_cap = spill_need;
   }
-  a.stack_spill = sc->stack_spill;
+  a.stack_spill = cx.stack_spill;
 
   WfArgs w;
   w.r = a; w.pool = pool; w.state = sc->wf_state; w.rays = sc->wf_rays; w.ctr = sc->wf_ctr; w.max_rays = (unsigned int)max_rays;

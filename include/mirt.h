@@ -126,8 +126,12 @@ typedef struct MirtStats {
   float trace_kernel_ms, render_ms;
   float build_ms;
   int32_t num_nodes;
+  /* mean trace-kernel time over the frames finished since the previous mirt_get_stats call, and their number */
+  float trace_kernel_ms_mean;
+  int32_t frames_timed;
 } MirtStats;
-/* Waits for the last render on its stream, then reports. */
+/* Waits for every frame in flight, then reports (and resets the running mean).  Up to four frames may be in flight on
+ * different streams: a scene keeps four sets of render workspaces and reuses one only when its frame has finished. */
 int mirt_get_stats(MirtScene* sc, MirtStats* out);
 
 /* ---- introspection for parity tests ----------------------------------------------------------- */
