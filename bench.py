@@ -7,7 +7,9 @@ One step = one frame of the hot path (trace + resolve, scene and BVH resident in
 BASELINE.json's headline workload, `tenthousand.txt` at 1920x1080, 16 samples per pixel.  With N > 1 (launched by
 torch.distributed.run, one process per GPU) the frame is cut into interleaved row stripes, every rank renders its
 stripes with a replicated BVH, and the 8-bit framebuffer is gathered to rank 0 over RCCL and re-interleaved there; the
-total work per frame is fixed ("strong" scaling).  Rank 0 prints ONE JSON line.
+total work per frame is fixed ("strong" scaling).  Consecutive frames are kept in flight on alternating streams (two on
+one GPU, four per GPU on several; `--serial` for one): the drain of a frame is a single lane's bounce chain, and the next
+frame's workgroups use the CUs it frees.  Rank 0 prints ONE JSON line.
 
 value        = rays of the whole frame / max-over-ranks wall time per frame  (Mrays/s; a ray = one hitNearest call with
                bounce != 0), counted by the kernel's counters variant in an untimed pass.
@@ -74,7 +76,8 @@ def main():
     ap.add_argument("--spp", type=int, default=16)
     ap.add_argument("--stripe-rows", type=int, default=4)
     ap.add_argument("--cpu-step", type=int, default=3, help="sub-sampling step of the CPU baseline (0 = skip)")
-    ap.add_argument("--frames-in-flight", type=int, default=3, help="consecutive frames overlapped on separate streams (1..4)")
+    ap.add_argument("--frames-in-flight", type=int, default=0,
+                    help="consecutive frames overlapped on separate streams (1..4; default 2 on one GPU, 4 on several)")
     ap.add_argument("--serial", action="store_true", help="one frame in flight (no overlap of consecutive frames)")
     ap.add_argument("--png", default=None, help="write the last frame here (rank 0)")
     args = ap.parse_args()
@@ -112,7 +115,8 @@ def main():
     gatherer = FrameGatherer(partition, rank, world, dev)
     # Frames in flight: consecutive frames go to alternating streams and buffers, so the next frame's workgroups fill
     # the CUs the draining frame frees (the drain of a frame is one lane's 16-bounce chain, ~8 ms of latency).
-    nfl = 1 if args.serial else max(1, min(4, args.frames_in_flight))
+    nfl = args.frames_in_flight if args.frames_in_flight > 0 else (2 if world == 1 else 4)
+    nfl = 1 if args.serial else max(1, min(4, nfl))
     streams = [torch.cuda.Stream(device=dev) for _ in range(nfl)]
     parts = [gatherer.new_part_buffer(dev) for _ in range(nfl)]
     part = parts[0]

@@ -2,6 +2,7 @@
 #include "scene_dev.h"
 #include "host_scene.h"
 
+#include <cmath>
 #include <cstring>
 #include <vector>
 
@@ -91,8 +92,17 @@ int mirt_scene_create(const MirtSceneDesc* d, int device, MirtScene** out)
     if (p.mat.roughness > 0.0f) sc->any_rough = true;
   }
   std::vector<LightDev> suns((size_t)d->num_suns), bulbs((size_t)d->num_bulbs);
-  for (int i = 0; i < d->num_suns; ++i) suns[i] = {d->suns[i].dir.x, d->suns[i].dir.y, d->suns[i].dir.z, d->suns[i].color.r, d->suns[i].color.g, d->suns[i].color.b};
-  for (int i = 0; i < d->num_bulbs; ++i) bulbs[i] = {d->bulbs[i].point.x, d->bulbs[i].point.y, d->bulbs[i].point.z, d->bulbs[i].color.r, d->bulbs[i].color.g, d->bulbs[i].color.b};
+  for (int i = 0; i < d->num_suns; ++i) {
+    const MirtVec3& v = d->suns[i].dir;
+    // vec3::normalize (vec3.cuh:72-82) -- this translation unit is built with -ffp-contract=off
+    const float mag = sqrtf(v.x * v.x + v.y * v.y + v.z * v.z);
+    float nx = 0.0f, ny = 0.0f, nz = 0.0f;
+    const float diff = fabsf(mag - 0.0f), largest = fmaxf(fabsf(mag), fabsf(0.0f));
+    const bool zero = (largest < 1e-6f) ? (diff < 1e-6f) : (diff / largest < 1e-6f);
+    if (!zero) { const float inv = 1.0f / mag; nx = v.x * inv; ny = v.y * inv; nz = v.z * inv; }
+    suns[i] = {v.x, v.y, v.z, d->suns[i].color.r, d->suns[i].color.g, d->suns[i].color.b, nx, ny, nz, 1.0f / nx, 1.0f / ny, 1.0f / nz};
+  }
+  for (int i = 0; i < d->num_bulbs; ++i) bulbs[i] = {d->bulbs[i].point.x, d->bulbs[i].point.y, d->bulbs[i].point.z, d->bulbs[i].color.r, d->bulbs[i].color.g, d->bulbs[i].color.b, 0, 0, 0, 0, 0, 0};
   sc->d.spheres = nullptr; sc->d.triangles = nullptr; sc->d.prim_refs = nullptr; sc->d.planes = nullptr; sc->d.suns = nullptr; sc->d.bulbs = nullptr;
 
   int rc = MIRT_OK;

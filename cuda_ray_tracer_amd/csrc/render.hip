@@ -138,7 +138,7 @@ __global__ void __launch_bounds__(RBLOCK, MIRT_WAVES_PER_SIMD) trace_kernel(cons
       // lanes that wait: to shade, or (finished) for a new sample while the frame still has some
       const int nwait = __popcll(__ballot(!S.trav && !S.batch_pending && (S.g >= 0 || !exhausted)));
       const int nlive = __popcll(__ballot(S.g >= 0));
-      const bool drain = exhausted && nlive <= DRAIN_LANES;
+      const bool drain = exhausted && nlive <= a.drain_lanes;
       if (nwait >= a.refill_k || (drain && nwait > 0)) break;
       // lanes whose batch ray finished move on to the next ray of their batch (cheap; done in groups)
       if (bm != 0 && (__popcll(bm) >= a.batch_k || tm == 0 || drain)) {
@@ -570,6 +570,8 @@ int render(MirtScene* sc, const MirtRenderParams* p, void* d_rgba8, void* d_rgba
   a.lds_depth = STACK_LDS;
   if (const char* e = getenv("MIRT_STACK_LDS_DEPTH")) { int k = atoi(e); if (k >= 0 && k <= STACK_LDS) a.lds_depth = k; }   // tests: force the spill path
   a.refill_k = 32;
+  a.drain_lanes = DRAIN_LANES;
+  if (const char* e = getenv("MIRT_DRAIN_LANES")) { int k = atoi(e); if (k >= 0 && k <= 64) a.drain_lanes = k; }
   a.batch_k = 8;
   if (const char* e = getenv("MIRT_BATCH_K")) { int k = atoi(e); if (k >= 1 && k <= 64) a.batch_k = k; }
   if (const char* e = getenv("MIRT_REFILL_K")) { int k = atoi(e); if (k >= 1 && k <= 64) a.refill_k = k; }

@@ -21,7 +21,9 @@ constexpr uint32_t REF_IDMASK = 0x3fffffffu;
 constexpr uint32_t REF_NONE = 0xffffffffu;   // empty scene / plane marker is separate
 
 struct PlaneDev { float nx, ny, nz, px, py, pz; float mat[11]; float pad; };   // 72 B
-struct LightDev { float x, y, z, r, g, b; };                                    // suns: direction; bulbs: position
+// suns: direction; bulbs: position.  n* = normalize(direction) and i* = 1 / n* for suns, computed on the host with the same
+// IEEE operations the kernels would use (vec3::normalize, bvh_traversal.cu:106), so shadow rays to suns need no sqrt/div.
+struct LightDev { float x, y, z, r, g, b; float nx, ny, nz, ix, iy, iz; };
 
 // Arguments of the trace kernel (passed by value in the kernarg segment: uniform, scalar loads)
 struct RenderArgs {
@@ -56,6 +58,7 @@ struct RenderArgs {
   int pending_slots;
   int refill_k;                   // leave the traversal loop when this many lanes wait to shade
   int lds_depth;                  // traversal-stack entries kept in LDS (<= the compiled STACK_LDS); deeper ones spill
+  int drain_lanes;                // a wave with at most this many live lanes and nothing left to fetch stops batching
   int batch_k;                    // start the next rays of ray batches when this many lanes wait for one
   unsigned long long* counters;   // MirtStats head (8 x u64) or null
   unsigned long long* prof;       // diagnostic build only (MIRT_PROF)

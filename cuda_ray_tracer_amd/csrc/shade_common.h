@@ -144,12 +144,12 @@ struct Lane {
 };
 
 // hitNearest's plane half (checkPlane, draw.cu:581-615) and the decision whether the BVH must be walked at all.
-template <bool COUNT>
+template <bool COUNT, bool HAVE_INV = false>
 MIRT_DEV void start_ray(const RenderArgs& a, Lane& S, Counters& cn)
 {
   const bool shadow = S.shadow;
   if (COUNT) { cn.rays++; if (shadow) cn.shadow_rays++; }
-  S.inv = mk3(1.0f / S.d.x, 1.0f / S.d.y, 1.0f / S.d.z);
+  if (!HAVE_INV) S.inv = mk3(1.0f / S.d.x, 1.0f / S.d.y, 1.0f / S.d.z);
   float tplane = INFINITY;
   int plane_id = -1;
   for (int i = 0; i < a.num_planes; ++i) {
@@ -183,18 +183,20 @@ MIRT_DEV void batch_next(const RenderArgs& a, Lane& S, Counters& cn)
   ++S.li;
   if (S.li < nlights) {
     // shadow ray, draw.cu:346 / 362-363
+    S.shadow = true;
     if (S.li < a.num_suns) {
+      // direction and its reciprocal are per-light constants (host-computed, same arithmetic)
       const LightDev& lt = a.suns[S.li];
-      set_ray(S, mkray(S.bo, mk3(lt.x, lt.y, lt.z), 1));
+      S.o = S.bo; S.d = mk3(lt.nx, lt.ny, lt.nz); S.inv = mk3(lt.ix, lt.iy, lt.iz); S.bounce = 1;
       S.limit = INFINITY;
+      start_ray<COUNT, true>(a, S, cn);
     } else {
       const LightDev& lt = a.bulbs[S.li - a.num_suns];
       const f3 bd = mk3(lt.x, lt.y, lt.z) - S.Hp;
       set_ray(S, mkray(S.bo, bd, 1));
       S.limit = length(bd);
+      start_ray<COUNT>(a, S, cn);
     }
-    S.shadow = true;
-    start_ray<COUNT>(a, S, cn);
   } else if (S.li == nlights && S.has_reflect) {
     S.o = S.bo; S.d = S.rdir; S.bounce = S.Hbounce - 1;
     S.shadow = false;
@@ -227,7 +229,7 @@ MIRT_DEV int advance_core(const RenderArgs& a, Lane& S, Counters& cn, const long
       if ((S.occl >> li) & 1ull) continue;
       if (li < a.num_suns) {
         const LightDev& lt = a.suns[li];
-        const float lambert = fmaxf(dot(S.pn, normalize(mk3(lt.x, lt.y, lt.z))), 0.0f);
+        const float lambert = fmaxf(dot(S.pn, mk3(lt.nx, lt.ny, lt.nz)), 0.0f);
         const float r = S.Hcolor.x * (lt.r * lambert), gg = S.Hcolor.y * (lt.g * lambert), b = S.Hcolor.z * (lt.b * lambert);
         Dacc = Dacc + mk3(set_expose(r, a.expose), set_expose(gg, a.expose), set_expose(b, a.expose));
       } else {

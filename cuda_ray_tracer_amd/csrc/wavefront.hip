@@ -216,7 +216,7 @@ __global__ void __launch_bounds__(SBLOCK, MIRT_WF_SHADE_WAVES) wf_shade_kernel(c
     // shadow rays (draw.cu:346 / 362-363), then the reflection ray (draw.cu:402)
     for (int j = 0; j < nlights; ++j) {
       f3 dir; float limit;
-      if (j < a.num_suns) { const LightDev& lt = a.suns[j]; dir = normalize(mk3(lt.x, lt.y, lt.z)); limit = INFINITY; }
+      if (j < a.num_suns) { const LightDev& lt = a.suns[j]; dir = mk3(lt.nx, lt.ny, lt.nz); limit = INFINITY; }
       else { const LightDev& lt = a.bulbs[j - a.num_suns]; const f3 bd = mk3(lt.x, lt.y, lt.z) - S.Hp; dir = normalize(bd); limit = length(bd); }
       const unsigned int q = first + (unsigned int)j;
       if (q < w.max_rays) {

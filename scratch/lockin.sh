@@ -2,12 +2,12 @@
 export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 cd $R
-timeout -k 10 600 python -m pytest tests -m gpu -x -q > gpurun_out/t5.log 2>&1; tail -3 gpurun_out/t5.log
-python bench.py > gpurun_out/bench2.json 2> gpurun_out/bench2.err; cat gpurun_out/bench2.json
+python bench.py > gpurun_out/bench3.json 2> gpurun_out/bench3.err; cat gpurun_out/bench3.json
+python bench.py --serial --cpu-step 0 > gpurun_out/bench3_serial.json 2>/dev/null; cat gpurun_out/bench3_serial.json
 cd /tmp
-timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_r01b -- python3 $R/bench.py --steps 5 --warmup 1 --cpu-step 0 > $R/gpurun_out/bench_prof2.json 2> $R/gpurun_out/bench_prof2.err
-timeout -k 10 200 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $R/gpurun_out/pmc_fetch -- python3 $R/bench.py --steps 2 --warmup 0 --cpu-step 0 > /dev/null 2>&1
-timeout -k 10 200 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $R/gpurun_out/pmc_write -- python3 $R/bench.py --steps 2 --warmup 0 --cpu-step 0 > /dev/null 2>&1
+timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_r01c -- python3 $R/bench.py --steps 6 --warmup 2 --cpu-step 0 > $R/gpurun_out/bench_prof3.json 2> $R/gpurun_out/bench_prof3.err
+timeout -k 10 200 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $R/gpurun_out/pmc_fetch3 -- python3 $R/bench.py --steps 3 --warmup 2 --cpu-step 0 --serial > /dev/null 2>&1
+timeout -k 10 200 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $R/gpurun_out/pmc_write3 -- python3 $R/bench.py --steps 3 --warmup 2 --cpu-step 0 --serial > /dev/null 2>&1
 cd $R
-cat gpurun_out/bench_prof2.json
-for s in spiral redchair; do python bench.py --scene $s --cpu-step 0 --steps 5 2>/dev/null; done
+cat gpurun_out/bench_prof3.json
+for s in spiral redchair; do python bench.py --scene $s --cpu-step 0 --steps 6 2>/dev/null; done

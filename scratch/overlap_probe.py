@@ -4,10 +4,10 @@ import cuda_ray_tracer_amd as m
 from cuda_ray_tracer_amd import api
 w, h, spp = 1920, 1080, 16
 stl = m.parseInput("scenes/tenthousand.txt"); raw = m.initRawConfigFromStl(stl, 0); m.build_lbvh_karas(raw)
-for parts in (1, 2, 4, 8):
+for parts in (8,):
     p = api.render_params(w, h, spp, 4 if parts > 1 else h, parts, 0)
     n = api.num_pixels(p)
-    for nfl in (1, 2):
+    for nfl in (2, 3, 4):
         streams = [torch.cuda.Stream() for _ in range(nfl)]
         bufs = [torch.empty(n * 4, dtype=torch.uint8, device="cuda") for _ in range(nfl)]
         K = 12
