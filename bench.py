@@ -96,11 +96,18 @@ def main():
         args.gpus = world
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product has no CPU path")
+    # MIRT_BENCH_REHEARSE=1: several ranks share GPU 0 over gloo -- exercises the N > 1 code path on a one-GPU box
+    rehearse = os.environ.get("MIRT_BENCH_REHEARSE") == "1"
+    if rehearse:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if rehearse:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     scene_file = os.path.join(ROOT, "scenes", args.scene + ".txt")
     W, H, SPP = args.width, args.height, args.spp
@@ -112,13 +119,14 @@ def main():
     stripe_rows = args.stripe_rows if world > 1 else H
     partition = StripePartition(W, H, stripe_rows, world)
     mine = partition.params(rank, SPP)
-    gatherer = FrameGatherer(partition, rank, world, dev)
-    # Frames in flight: consecutive frames go to alternating streams and buffers, so the next frame's workgroups fill
-    # the CUs the draining frame frees (the drain of a frame is one lane's 16-bounce chain, ~8 ms of latency).
+    # Frames in flight: consecutive frames go to alternating streams, each with its own part buffer and (on rank 0) its own
+    # gather buffers and frame, so the next frame's workgroups fill the CUs the draining frame frees (the drain of a frame
+    # is one lane's 16-bounce chain, ~8 ms of latency).
     nfl = args.frames_in_flight if args.frames_in_flight > 0 else (2 if world == 1 else 4)
     nfl = 1 if args.serial else max(1, min(4, nfl))
     streams = [torch.cuda.Stream(device=dev) for _ in range(nfl)]
-    parts = [gatherer.new_part_buffer(dev) for _ in range(nfl)]
+    gatherers = [FrameGatherer(partition, rank, world, dev) for _ in range(nfl)]
+    parts = [g.new_part_buffer(dev) for g in gatherers]
     part = parts[0]
     frame_no = [0]
 
@@ -128,16 +136,17 @@ def main():
         with torch.cuda.stream(streams[i]):
             m.render(parts[i], W, H, SPP, raw, params=mine)
             if world > 1:
-                return gatherer.gather(parts[i])   # RCCL gather over xGMI (<= 1.04 MB per rank at 1080p) + re-interleave on rank 0
-        return parts[i]                            # N = 1: the part already is the whole row-major frame
+                return gatherers[i].gather(parts[i])   # RCCL gather over xGMI (<= 1.04 MB per rank at 1080p) + re-interleave on rank 0
+        return parts[i]                                # N = 1: the part already is the whole row-major frame
 
     # untimed counting pass (same rays every frame: the RNG is keyed by pixel and sample index only)
     cparams = partition.params(rank, SPP, counters=True)
     m.render(part, W, H, SPP, raw, params=cparams)
     torch.cuda.synchronize()
     cst = raw.stats()
+    cdev = torch.device("cpu") if rehearse else dev
     counts = torch.tensor([cst[k] for k in ("rays", "internal_visits", "sphere_tests", "tri_tests", "mat_fetches", "samples")],
-                          dtype=torch.float64, device=dev)
+                          dtype=torch.float64, device=cdev)
     if world > 1:
         dist.all_reduce(counts)
     total_rays = float(counts[0].item())
@@ -156,10 +165,16 @@ def main():
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     kst = raw.stats()
-    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+    tmax = torch.tensor([dt], dtype=torch.float64, device=cdev)
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax.item())
+
+    if args.png:                      # one more frame (a collective on several GPUs: every rank takes part)
+        fr = step()
+        torch.cuda.synchronize()
+        if rank == 0:
+            m.write_png(args.png, fr[: W * H * 4].cpu().numpy(), W, H)
 
     if rank == 0:
         ms_per_step = dt / args.steps * 1e3
@@ -192,10 +207,6 @@ def main():
             out["cpu_baseline"] = cpu_baseline(scene_file, W, H, SPP, args.cpu_step)
         else:
             out["cpu_baseline"] = None
-        if args.png:
-            fr = step()
-            torch.cuda.synchronize()
-            m.write_png(args.png, fr[: W * H * 4].cpu().numpy(), W, H)
         print(json.dumps(out), flush=True)
 
     raw.close()

@@ -57,7 +57,16 @@ class FrameGatherer:
     def gather(self, part_buf):
         """part_buf: this rank's compact stripes, padded to max_bytes.  Returns the frame on rank 0, None elsewhere."""
         if self.world > 1:
-            dist.gather(part_buf, self.gathered if self.rank == 0 else None, dst=0, group=self.group)
+            if part_buf.is_cuda and dist.get_backend(self.group) == "gloo":
+                # rehearsal only (several ranks sharing one GPU, where RCCL refuses duplicate devices): stage through the host
+                host = part_buf.cpu()
+                got = [torch.empty_like(host) for _ in range(self.world)] if self.rank == 0 else None
+                dist.gather(host, got, dst=0, group=self.group)
+                if self.rank == 0:
+                    for r in range(self.world):
+                        self.gathered[r].copy_(got[r])
+            else:
+                dist.gather(part_buf, self.gathered if self.rank == 0 else None, dst=0, group=self.group)
         if self.rank != 0:
             return None
         fr = self.frame.view(self.p.height, self.row_bytes)
