@@ -33,16 +33,19 @@ MIRT_DEV bool fequal(float a, float b)
   return diff / largest < 1e-6f;
 }
 MIRT_DEV float length(const f3& v) { return sqrtf(v.x * v.x + v.y * v.y + v.z * v.z); }
+// fequal(x, 0) (vec3.cuh:7-18) without its division: largest = |x|; below 1e-6 the answer is |x| < 1e-6 = true, otherwise it
+// is |x|/|x| < 1e-6 = false (inf/inf and NaN compare false on both routes) -- so it is exactly |x| < 1e-6.
+MIRT_DEV bool is_zero(float x) { return fabsf(x) < 1e-6f; }
 // vec3.cuh:72-82
 MIRT_DEV f3 normalize(const f3& v)
 {
   float mag = length(v);
-  if (fequal(mag, 0.0f)) return mk3(0.0f, 0.0f, 0.0f);
+  if (is_zero(mag)) return mk3(0.0f, 0.0f, 0.0f);
   float inv = 1.0f / mag;
   return mk3(v.x * inv, v.y * inv, v.z * inv);
 }
 // RGB == RGB(0,0,0), struct.cuh:20-23
-MIRT_DEV bool is_black(const f3& c) { return fequal(c.x, 0.0f) && fequal(c.y, 0.0f) && fequal(c.z, 0.0f); }
+MIRT_DEV bool is_black(const f3& c) { return is_zero(c.x) && is_zero(c.y) && is_zero(c.z); }
 
 // ---- deterministic transcendental functions -----------------------------------------------------
 MIRT_DEV double dm_frombits(uint64_t b) { return __longlong_as_double((long long)b); }

@@ -57,7 +57,7 @@ __global__ void __launch_bounds__(RBLOCK, MIRT_WAVES_PER_SIMD) trace_kernel(cons
   (void)lane;
   unsigned char* const stage = lds_raw + STACK_LDS * RBLOCK * 4 + __builtin_amdgcn_readfirstlane(tid >> 6) * STAGE_WAVE_BYTES;
   const unsigned char* const heap = reinterpret_cast<const unsigned char*>(a.nodes);
-  (void)stage; (void)heap;
+  (void)stage;
   const long long gid = (long long)blockIdx.x * RBLOCK + tid;
   const long long gthreads = (long long)gridDim.x * RBLOCK;
   Counters cn = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -178,8 +178,10 @@ __global__ void __launch_bounds__(RBLOCK, MIRT_WAVES_PER_SIMD) trace_kernel(cons
         const float4* rec = reinterpret_cast<const float4*>(stage + (lane & 3) * STAGE_ROUND_BYTES + (lane & ~3) * 16);
         const float4 q0 = rec[0], q1 = rec[1], q2 = rec[2], q3 = rec[3];
 #else
+        // one base pointer (the record heap) + a 32-bit byte offset: scalar base, 32-bit vector offset loads
         const uint32_t id = S.cur & REF_IDMASK;
-        const float4* rec = leaf ? (tri ? a.tris + 3 * (size_t)id : a.spheres + id) : a.nodes + 4 * (size_t)S.cur;
+        const uint32_t roff = leaf ? (tri ? a.tri_base + 48u * id : a.sph_base + 16u * id) : 64u * S.cur;
+        const float4* rec = reinterpret_cast<const float4*>(heap + roff);
         const float4 q0 = rec[0];
         float4 q1 = make_float4(0, 0, 0, 0), q2 = q1, q3 = q1;
         if (!leaf || tri) { q1 = rec[1]; q2 = rec[2]; }
@@ -249,8 +251,10 @@ __global__ void __launch_bounds__(RBLOCK, MIRT_WAVES_PER_SIMD) trace_kernel(cons
             S.cur = lref;
             // push right: the previous top of stack goes to memory, the new top stays in a register
             if (S.sp < STACK_TOTAL) {
-              if (S.sp > 0) {
-                const int slot = S.sp - 1;
+              {
+                // the previous top goes to memory.  For an empty stack this writes a dead value to slot 0, which is
+                // rewritten before anything reads it -- one branch less in the hot loop.
+                const int slot = S.sp > 0 ? S.sp - 1 : 0;
                 if (slot < a.lds_depth) lds_stack[slot * RBLOCK + tid] = S.tos;
                 else a.stack_spill[(size_t)(slot - a.lds_depth) * gthreads + gid] = S.tos;
               }
@@ -267,8 +271,9 @@ __global__ void __launch_bounds__(RBLOCK, MIRT_WAVES_PER_SIMD) trace_kernel(cons
           else {
             S.cur = S.tos;
             --S.sp;
-            if (S.sp > 0) {
-              const int slot = S.sp - 1;
+            {
+              // reload the new top (a dead read of slot 0 when the stack is now empty)
+              const int slot = S.sp > 0 ? S.sp - 1 : 0;
               S.tos = lds_stack[(slot < a.lds_depth ? slot : 0) * RBLOCK + tid];
               if (slot >= a.lds_depth) S.tos = a.stack_spill[(size_t)(slot - a.lds_depth) * gthreads + gid];
             }
@@ -495,6 +500,9 @@ int render(MirtScene* sc, const MirtRenderParams* p, void* d_rgba8, void* d_rgba
   if (npix < 0 || p->spp < 0 || !d_rgba8) { set_error("mirt_render: bad parameters"); return MIRT_ERR_ARG; }
   if ((int64_t)p->width * p->height > 0x7fffffffll - 1234) { set_error("mirt_render: frame too large for the 32-bit pixel seed"); return MIRT_ERR_ARG; }
   if (npix == 0) return MIRT_OK;
+  if ((long long)npix * (p->spp > 1 ? p->spp : 1) >= 0xffffffffll || (long long)p->stripe_rows * p->width >= 0x7fffffffll) {
+    set_error("mirt_render: more than 2^32 samples in one call; render the frame in parts"); return MIRT_ERR_ARG;
+  }
   const int sppe = p->spp > 1 ? p->spp : 1;
   const long long nsamples = (long long)npix * sppe;
   const bool count = (p->flags & MIRT_RENDER_COUNTERS) != 0;

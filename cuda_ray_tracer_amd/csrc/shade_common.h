@@ -424,15 +424,18 @@ MIRT_DEV void advance(const RenderArgs& a, Lane& S, Counters& cn, const long lon
 template <bool COUNT>
 MIRT_DEV void init_sample_core(const RenderArgs& a, Lane& S, Counters& cn, const long long idx)
 {
-  const int sppe = a.spp > 1 ? a.spp : 1;
-  const long long stripe_pixels = (long long)a.stripe_rows * a.width;
-  const long long lp = idx / sppe;
-  const int sidx = (int)(idx - lp * sppe);
-  const long long ls = lp / stripe_pixels;
-  const long long within = lp - ls * stripe_pixels;
-  const long long gs = ls * a.num_parts + a.part;
-  const int py = (int)(gs * a.stripe_rows + within / a.width);
-  const int px = (int)(within % a.width);
+  // sample -> local pixel -> frame pixel, in 32-bit arithmetic (render() guarantees num_samples < 2^32)
+  const uint32_t sppe = a.spp > 1 ? (uint32_t)a.spp : 1u;
+  const uint32_t stripe_pixels = (uint32_t)a.stripe_rows * (uint32_t)a.width;
+  const uint32_t i32 = (uint32_t)idx;
+  const uint32_t lp = i32 / sppe;
+  const int sidx = (int)(i32 - lp * sppe);
+  const uint32_t ls = lp / stripe_pixels;
+  const uint32_t within = lp - ls * stripe_pixels;
+  const uint32_t gs = ls * (uint32_t)a.num_parts + (uint32_t)a.part;
+  const uint32_t wy = within / (uint32_t)a.width;
+  const int py = (int)(gs * (uint32_t)a.stripe_rows + wy);
+  const int px = (int)(within - wy * (uint32_t)a.width);
   const uint32_t pixel = (uint32_t)py * (uint32_t)a.width + (uint32_t)px;
   S.g = idx;
   S.steps = 0;

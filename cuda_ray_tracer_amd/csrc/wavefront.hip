@@ -365,7 +365,8 @@ __global__ void __launch_bounds__(WBLOCK, MIRT_WF_WAVES_PER_SIMD) wf_trace_kerne
       const bool tri = leaf && (cur & REF_TRI);
 #if !MIRT_WF_QUAD_FETCH
       const uint32_t id = cur & REF_IDMASK;
-      const float4* rec = leaf ? (tri ? a.tris + 3 * (size_t)id : a.spheres + id) : a.nodes + 4 * (size_t)cur;
+      const uint32_t roff = leaf ? (tri ? a.tri_base + 48u * id : a.sph_base + 16u * id) : 64u * cur;
+      const float4* rec = reinterpret_cast<const float4*>(reinterpret_cast<const unsigned char*>(a.nodes) + roff);
       const float4 q0 = rec[0];
       float4 q1 = make_float4(0, 0, 0, 0), q2 = q1, q3 = q1;
       if (!leaf || tri) { q1 = rec[1]; q2 = rec[2]; }
