@@ -44,9 +44,9 @@ constexpr int STACK_LDS = MIRT_STACK_LDS;
 constexpr int STAGE_ROUND_BYTES = 64 * 16 + 16;          // +16: rounds land on different LDS bank phases (conflict-free ds_read_b128)
 constexpr int STAGE_WAVE_BYTES = MIRT_QUAD_FETCH ? 4 * STAGE_ROUND_BYTES : 0;
 template <bool COUNT, bool PROF>
-__global__ void __launch_bounds__(RBLOCK, MIRT_WAVES_PER_SIMD) trace_kernel(const RenderArgs a)
+__global__ void __launch_bounds__(RBLOCK, MIRT_WAVES_PER_SIMD) trace_kernel(const RenderArgs* __restrict__ ap, const HotArgs h)
 {
-  // PROF: diagnostic build only -- cycle stamps per phase, written to a.prof (never used for timing claims)
+  // PROF: diagnostic build only -- cycle stamps per phase, written to h.prof (never used for timing claims)
   unsigned long long pf_S = 0, pf_T = 0, pf_iters = 0, pf_active = 0, pf_Sent = 0, pf_Slanes = 0, pf_Bent = 0, pf_Blanes = 0, pf_leaf = 0, pf_node = 0;
   const unsigned long long pf_t0 = PROF ? clock64() : 0;
   // One LDS array: [traversal stacks: STACK_LDS x RBLOCK words][per-wave record staging: 4 rounds x (64 x 16 B + 16 B pad)]
@@ -56,7 +56,7 @@ __global__ void __launch_bounds__(RBLOCK, MIRT_WAVES_PER_SIMD) trace_kernel(cons
   const int lane = tid & 63;
   (void)lane;
   unsigned char* const stage = lds_raw + STACK_LDS * RBLOCK * 4 + __builtin_amdgcn_readfirstlane(tid >> 6) * STAGE_WAVE_BYTES;
-  const unsigned char* const heap = reinterpret_cast<const unsigned char*>(a.nodes);
+  const unsigned char* const heap = reinterpret_cast<const unsigned char*>(h.nodes);
   (void)stage;
   const long long gid = (long long)blockIdx.x * RBLOCK + tid;
   const long long gthreads = (long long)gridDim.x * RBLOCK;
@@ -66,7 +66,7 @@ __global__ void __launch_bounds__(RBLOCK, MIRT_WAVES_PER_SIMD) trace_kernel(cons
   // takes the next chunk from a global counter whenever its local one is used up (one atomic per chunk), so waves that
   // draw cheap samples simply draw more of them -- this is what keeps the tail short when a GPU renders only a stripe set.
   unsigned long long c_next = 0, c_end = 0;   // wave-uniform: this wave's current chunk
-  const unsigned long long nchunks = ((unsigned long long)a.num_samples + WORK_CHUNK - 1) / WORK_CHUNK;
+  const unsigned long long nchunks = ((unsigned long long)h.num_samples + WORK_CHUNK - 1) / WORK_CHUNK;
   bool exhausted = false;                      // wave-uniform: the global counter has run past the frame
 
   Lane S;
@@ -86,6 +86,11 @@ __global__ void __launch_bounds__(RBLOCK, MIRT_WAVES_PER_SIMD) trace_kernel(cons
     // ================= shade / refill phase: lanes that are not traversing =================
     unsigned long long pf_a = 0;
     if (PROF) { pf_a = clock64(); pf_Sent++; pf_Slanes += __popcll(__ballot(!S.trav && S.g >= 0)); }
+    // The shade phase reads the frame's RenderArgs through a pointer the optimiser cannot see through, so that those
+    // values are (scalar-)loaded here and do not live in registers across the traversal loop.
+    const RenderArgs* aq = ap;
+    asm volatile("" : "+s"(aq));
+    const RenderArgs& a = *aq;
     while (!S.trav && S.g >= 0) {
       if (S.batch_pending) batch_next<COUNT>(a, S, cn);
       else advance<COUNT>(a, S, cn, gid, gthreads);
@@ -101,14 +106,14 @@ __global__ void __launch_bounds__(RBLOCK, MIRT_WAVES_PER_SIMD) trace_kernel(cons
           if (c_next >= c_end) {
             unsigned long long k = 0;
             if (lane == 0) {
-              k = atomicAdd(a.work_counter, 1ull);
+              k = atomicAdd(h.work_counter, 1ull);
               // longest-first hand-out order measured on an earlier frame (any order gives the same pixels)
-              if (k < nchunks && a.chunk_order) k = a.chunk_order[k];
+              if (k < nchunks && h.chunk_order) k = h.chunk_order[k];
             }
             k = __shfl(k, 0);
             if (k >= nchunks) { exhausted = true; break; }
             c_next = k * WORK_CHUNK;
-            c_end = (c_next + WORK_CHUNK < (unsigned long long)a.num_samples) ? c_next + WORK_CHUNK : (unsigned long long)a.num_samples;
+            c_end = (c_next + WORK_CHUNK < (unsigned long long)h.num_samples) ? c_next + WORK_CHUNK : (unsigned long long)h.num_samples;
           }
           const int avail = (int)(c_end - c_next);
           const int take = (want - given < avail) ? want - given : avail;
@@ -138,12 +143,12 @@ __global__ void __launch_bounds__(RBLOCK, MIRT_WAVES_PER_SIMD) trace_kernel(cons
       // lanes that wait: to shade, or (finished) for a new sample while the frame still has some
       const int nwait = __popcll(__ballot(!S.trav && !S.batch_pending && (S.g >= 0 || !exhausted)));
       const int nlive = __popcll(__ballot(S.g >= 0));
-      const bool drain = exhausted && nlive <= a.drain_lanes;
-      if (nwait >= a.refill_k || (drain && nwait > 0)) break;
+      const bool drain = exhausted && nlive <= h.drain_lanes;
+      if (nwait >= h.refill_k || (drain && nwait > 0)) break;
       // lanes whose batch ray finished move on to the next ray of their batch (cheap; done in groups)
-      if (bm != 0 && (__popcll(bm) >= a.batch_k || tm == 0 || drain)) {
+      if (bm != 0 && (__popcll(bm) >= h.batch_k || tm == 0 || drain)) {
         if (PROF) { pf_Bent++; pf_Blanes += __popcll(bm); }
-        if (!S.trav && S.batch_pending) batch_next<COUNT>(a, S, cn);
+        if (!S.trav && S.batch_pending) batch_next<COUNT>(h, S, cn);
       }
       if (PROF) { pf_iters++; pf_active += __popcll(__ballot(S.trav)); pf_leaf += __popcll(__ballot(S.trav && (S.cur & REF_LEAF))); }
 #if MIRT_QUAD_FETCH
@@ -154,7 +159,7 @@ __global__ void __launch_bounds__(RBLOCK, MIRT_WAVES_PER_SIMD) trace_kernel(cons
         uint32_t off = 0xffffffffu;
         if (S.trav) {
           const uint32_t id0 = S.cur & REF_IDMASK;
-          off = (S.cur & REF_LEAF) ? ((S.cur & REF_TRI) ? a.tri_base + 48u * id0 : a.sph_base + 16u * id0) : 64u * S.cur;
+          off = (S.cur & REF_LEAF) ? ((S.cur & REF_TRI) ? h.tri_base + 48u * id0 : h.sph_base + 16u * id0) : 64u * S.cur;
         }
         const uint32_t sub = (uint32_t)(lane & 3) * 16u;
 #define MIRT_FETCH_ROUND(j)                                                                                                    \
@@ -180,7 +185,7 @@ __global__ void __launch_bounds__(RBLOCK, MIRT_WAVES_PER_SIMD) trace_kernel(cons
 #else
         // one base pointer (the record heap) + a 32-bit byte offset: scalar base, 32-bit vector offset loads
         const uint32_t id = S.cur & REF_IDMASK;
-        const uint32_t roff = leaf ? (tri ? a.tri_base + 48u * id : a.sph_base + 16u * id) : 64u * S.cur;
+        const uint32_t roff = leaf ? (tri ? h.tri_base + 48u * id : h.sph_base + 16u * id) : 64u * S.cur;
         const float4* rec = reinterpret_cast<const float4*>(heap + roff);
         const float4 q0 = rec[0];
         float4 q1 = make_float4(0, 0, 0, 0), q2 = q1, q3 = q1;
@@ -255,8 +260,8 @@ __global__ void __launch_bounds__(RBLOCK, MIRT_WAVES_PER_SIMD) trace_kernel(cons
                 // the previous top goes to memory.  For an empty stack this writes a dead value to slot 0, which is
                 // rewritten before anything reads it -- one branch less in the hot loop.
                 const int slot = S.sp > 0 ? S.sp - 1 : 0;
-                if (slot < a.lds_depth) lds_stack[slot * RBLOCK + tid] = S.tos;
-                else a.stack_spill[(size_t)(slot - a.lds_depth) * gthreads + gid] = S.tos;
+                if (slot < h.lds_depth) lds_stack[slot * RBLOCK + tid] = S.tos;
+                else h.stack_spill[(size_t)(slot - h.lds_depth) * gthreads + gid] = S.tos;
               }
               S.tos = rref;
               ++S.sp;
@@ -274,8 +279,8 @@ __global__ void __launch_bounds__(RBLOCK, MIRT_WAVES_PER_SIMD) trace_kernel(cons
             {
               // reload the new top (a dead read of slot 0 when the stack is now empty)
               const int slot = S.sp > 0 ? S.sp - 1 : 0;
-              S.tos = lds_stack[(slot < a.lds_depth ? slot : 0) * RBLOCK + tid];
-              if (slot >= a.lds_depth) S.tos = a.stack_spill[(size_t)(slot - a.lds_depth) * gthreads + gid];
+              S.tos = lds_stack[(slot < h.lds_depth ? slot : 0) * RBLOCK + tid];
+              if (slot >= h.lds_depth) S.tos = h.stack_spill[(size_t)(slot - h.lds_depth) * gthreads + gid];
             }
           }
         }
@@ -284,15 +289,15 @@ __global__ void __launch_bounds__(RBLOCK, MIRT_WAVES_PER_SIMD) trace_kernel(cons
     if (PROF) pf_T += clock64() - pf_b;
   }
   (void)lane;
-  if (PROF && a.prof && (tid & 63) == 0) {
+  if (PROF && h.prof && (tid & 63) == 0) {
     const unsigned long long tot = clock64() - pf_t0;
-    atomicAdd(&a.prof[0], tot); atomicAdd(&a.prof[1], pf_S); atomicAdd(&a.prof[2], pf_T); atomicAdd(&a.prof[3], pf_iters);
-    atomicAdd(&a.prof[4], pf_active); atomicAdd(&a.prof[5], pf_Sent); atomicAdd(&a.prof[6], pf_Slanes); atomicAdd(&a.prof[7], pf_Bent);
-    atomicAdd(&a.prof[8], pf_Blanes); atomicAdd(&a.prof[9], pf_leaf); atomicAdd(&a.prof[10], 1ull);
+    atomicAdd(&h.prof[0], tot); atomicAdd(&h.prof[1], pf_S); atomicAdd(&h.prof[2], pf_T); atomicAdd(&h.prof[3], pf_iters);
+    atomicAdd(&h.prof[4], pf_active); atomicAdd(&h.prof[5], pf_Sent); atomicAdd(&h.prof[6], pf_Slanes); atomicAdd(&h.prof[7], pf_Bent);
+    atomicAdd(&h.prof[8], pf_Blanes); atomicAdd(&h.prof[9], pf_leaf); atomicAdd(&h.prof[10], 1ull);
   }
   (void)pf_node;
 
-  if (COUNT && a.counters) {
+  if (COUNT && h.counters) {
     uint32_t v[8] = {cn.samples, cn.rays, cn.shadow_rays, cn.internal_visits, cn.sphere_tests, cn.tri_tests, cn.mat_fetches, cn.max_stack};
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
@@ -300,11 +305,11 @@ __global__ void __launch_bounds__(RBLOCK, MIRT_WAVES_PER_SIMD) trace_kernel(cons
       if (k == 7) {
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) { unsigned long long y = __shfl_xor(x, off); x = x > y ? x : y; }
-        if ((tid & 63) == 0) atomicMax(&a.counters[k], x);
+        if ((tid & 63) == 0) atomicMax(&h.counters[k], x);
       } else {
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) x += __shfl_xor(x, off);
-        if ((tid & 63) == 0) atomicAdd(&a.counters[k], x);
+        if ((tid & 63) == 0) atomicAdd(&h.counters[k], x);
       }
     }
   }
@@ -627,19 +632,30 @@ int render(MirtScene* sc, const MirtRenderParams* p, void* d_rgba8, void* d_rgba
     int rc = wavefront_trace(sc, cx, a, count, stream, &tms);
     if (rc != MIRT_OK) return rc;
     cx.wf_trace_ms = tms;
-  } else if (prof) {
-    if (!cx.prof) MIRT_HIP(hipMalloc(&cx.prof, 16 * sizeof(unsigned long long)));
-    MIRT_HIP(hipMemsetAsync(cx.prof, 0, 16 * sizeof(unsigned long long), stream));
-    a.prof = cx.prof;
-    hipLaunchKernelGGL((trace_kernel<false, true>), dim3(blocks), dim3(RBLOCK), 0, stream, a);
-    MIRT_HIP(hipStreamSynchronize(stream));
-    unsigned long long h[16];
-    MIRT_HIP(hipMemcpy(h, cx.prof, sizeof(h), hipMemcpyDeviceToHost));
-    fprintf(stderr, "[mirt prof] waves=%llu cyc/wave=%.3g S=%.1f%% T=%.1f%% | T-iters/wave=%.0f active/iter=%.1f leaf-lanes/iter=%.1f | S-entries/wave=%.0f lanes/entry=%.1f | B-entries/wave=%.0f lanes/entry=%.1f\n",
-            h[10], (double)h[0] / h[10], 100.0 * h[1] / h[0], 100.0 * h[2] / h[0], (double)h[3] / h[10], (double)h[4] / (h[3] ? h[3] : 1), (double)h[9] / (h[3] ? h[3] : 1),
-            (double)h[5] / h[10], (double)h[6] / (h[5] ? h[5] : 1), (double)h[7] / h[10], (double)h[8] / (h[7] ? h[7] : 1));
-  } else if (count) hipLaunchKernelGGL((trace_kernel<true, false>), dim3(blocks), dim3(RBLOCK), 0, stream, a);
-  else hipLaunchKernelGGL((trace_kernel<false, false>), dim3(blocks), dim3(RBLOCK), 0, stream, a);
+  } else {
+    HotArgs h;
+    h.nodes = a.nodes; h.sph_base = a.sph_base; h.tri_base = a.tri_base; h.root_ref = a.root_ref;
+    h.planes = a.planes; h.num_planes = a.num_planes; h.suns = a.suns; h.num_suns = a.num_suns; h.bulbs = a.bulbs; h.num_bulbs = a.num_bulbs;
+    h.stack_spill = a.stack_spill; h.lds_depth = a.lds_depth; h.refill_k = a.refill_k; h.batch_k = a.batch_k; h.drain_lanes = a.drain_lanes;
+    h.num_samples = a.num_samples; h.work_counter = a.work_counter; h.chunk_order = a.chunk_order; h.counters = a.counters; h.prof = nullptr;
+    if (!cx.args_dev) MIRT_HIP(hipMalloc(&cx.args_dev, sizeof(RenderArgs)));
+    if (prof) {
+      if (!cx.prof) MIRT_HIP(hipMalloc(&cx.prof, 16 * sizeof(unsigned long long)));
+      MIRT_HIP(hipMemsetAsync(cx.prof, 0, 16 * sizeof(unsigned long long), stream));
+      a.prof = cx.prof; h.prof = cx.prof;
+    }
+    MIRT_HIP(hipMemcpyAsync(cx.args_dev, &a, sizeof(RenderArgs), hipMemcpyHostToDevice, stream));
+    if (prof) {
+      hipLaunchKernelGGL((trace_kernel<false, true>), dim3(blocks), dim3(RBLOCK), 0, stream, cx.args_dev, h);
+      MIRT_HIP(hipStreamSynchronize(stream));
+      unsigned long long hh[16];
+      MIRT_HIP(hipMemcpy(hh, cx.prof, sizeof(hh), hipMemcpyDeviceToHost));
+      fprintf(stderr, "[mirt prof] waves=%llu cyc/wave=%.3g S=%.1f%% T=%.1f%% | T-iters/wave=%.0f active/iter=%.1f leaf-lanes/iter=%.1f | S-entries/wave=%.0f lanes/entry=%.1f | B-entries/wave=%.0f lanes/entry=%.1f\n",
+              hh[10], (double)hh[0] / hh[10], 100.0 * hh[1] / hh[0], 100.0 * hh[2] / hh[0], (double)hh[3] / hh[10], (double)hh[4] / (hh[3] ? hh[3] : 1), (double)hh[9] / (hh[3] ? hh[3] : 1),
+              (double)hh[5] / hh[10], (double)hh[6] / (hh[5] ? hh[5] : 1), (double)hh[7] / hh[10], (double)hh[8] / (hh[7] ? hh[7] : 1));
+    } else if (count) hipLaunchKernelGGL((trace_kernel<true, false>), dim3(blocks), dim3(RBLOCK), 0, stream, cx.args_dev, h);
+    else hipLaunchKernelGGL((trace_kernel<false, false>), dim3(blocks), dim3(RBLOCK), 0, stream, cx.args_dev, h);
+  }
   MIRT_HIP(hipGetLastError());
   MIRT_HIP(hipEventRecord(cx.ev2, stream));
 

@@ -67,6 +67,24 @@ struct RenderArgs {
   uint32_t* chunk_cost;             // per chunk: the largest number of traversal steps one of its samples took
 };
 
+// What the traversal loop of the single-kernel path touches, passed by value (scalar registers).  Everything else is read
+// through a pointer to the RenderArgs in device memory, and only inside the shade phase, so that it does not occupy
+// scalar registers across the hot loop.
+struct HotArgs {
+  const float4* nodes;            // start of the record heap
+  uint32_t sph_base, tri_base, root_ref;
+  const PlaneDev* planes; int num_planes;
+  const LightDev* suns; int num_suns;
+  const LightDev* bulbs; int num_bulbs;
+  uint32_t* stack_spill;
+  int lds_depth, refill_k, batch_k, drain_lanes;
+  long long num_samples;
+  unsigned long long* work_counter;
+  const uint32_t* chunk_order;
+  unsigned long long* counters;
+  unsigned long long* prof;
+};
+
 struct ResolveArgs {
   const float4* samples;
   unsigned char* rgba8;
@@ -90,6 +108,7 @@ struct RenderCtx {
   float* pending = nullptr; size_t pending_cap = 0;
   unsigned long long* counters = nullptr;  // device: [0..7] MirtStats counters, [8] work counter
   unsigned long long* prof = nullptr;      // diagnostic stamps (MIRT_PROF)
+  RenderArgs* args_dev = nullptr;          // this frame's RenderArgs in device memory
   hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr, ev3 = nullptr;   // render start / trace start / trace end / render end
   bool used = false, counted = false, timed = true;
   // longest-first scheduling: this frame's per-chunk cost, and the hand-out orders computed from it (two buffers used in

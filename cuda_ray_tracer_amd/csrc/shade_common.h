@@ -144,8 +144,8 @@ struct Lane {
 };
 
 // hitNearest's plane half (checkPlane, draw.cu:581-615) and the decision whether the BVH must be walked at all.
-template <bool COUNT, bool HAVE_INV = false>
-MIRT_DEV void start_ray(const RenderArgs& a, Lane& S, Counters& cn)
+template <bool COUNT, bool HAVE_INV = false, typename Args = RenderArgs>
+MIRT_DEV void start_ray(const Args& a, Lane& S, Counters& cn)
 {
   const bool shadow = S.shadow;
   if (COUNT) { cn.rays++; if (shadow) cn.shadow_rays++; }
@@ -172,8 +172,8 @@ MIRT_DEV void set_ray(Lane& S, const RayS& r) { S.o = r.o; S.d = r.d; S.bounce =
 // The ray of the batch that was in flight has finished: note a shadow result, start the next ray of the batch
 // (shadow rays of diffuseLight, draw.cu:342-374, then the reflection ray of reflectionLight, draw.cu:402-404).
 // Shadow rays consume no random numbers, so tracing them after the reflection direction was drawn changes nothing.
-template <bool COUNT>
-MIRT_DEV void batch_next(const RenderArgs& a, Lane& S, Counters& cn)
+template <bool COUNT, typename Args = RenderArgs>
+MIRT_DEV void batch_next(const Args& a, Lane& S, Counters& cn)
 {
   const int nlights = a.num_suns + a.num_bulbs;
   if (S.li >= 0 && S.li < nlights) {
