@@ -18,7 +18,8 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "_build", "libmirt.so")
+# MIRT_LIB: load another build of the same library (tools/ab.py builds A/B variants next to the default one)
+LIB_PATH = os.environ.get("MIRT_LIB") or os.path.join(HERE, "_build", "libmirt.so")
 
 MIRT_RENDER_COUNTERS = 1
 

@@ -38,6 +38,9 @@ constexpr int DRAIN_LANES = 16;       // a wave with this few live lanes (and no
 #define MIRT_STACK_LDS 32
 #endif
 constexpr int STACK_LDS = MIRT_STACK_LDS;
+#ifndef MIRT_EARLY_CHILD
+#define MIRT_EARLY_CHILD 0
+#endif
 #ifndef MIRT_QUAD_FETCH
 #define MIRT_QUAD_FETCH 0   // measured on MI355X: 77.5 ms vs 68.1 ms without (the LDS round trip adds latency; TA is not the limiter)
 #endif
@@ -51,6 +54,9 @@ __global__ void __launch_bounds__(RBLOCK, MIRT_WAVES_PER_SIMD) trace_kernel(cons
   const unsigned long long pf_t0 = PROF ? clock64() : 0;
   // One LDS array: [traversal stacks: STACK_LDS x RBLOCK words][per-wave record staging: 4 rounds x (64 x 16 B + 16 B pad)]
   __shared__ __attribute__((aligned(16))) unsigned char lds_raw[STACK_LDS * RBLOCK * 4 + (RBLOCK / 64) * STAGE_WAVE_BYTES];
+  // The random-number state (8 words per lane) is only touched in the shade phase: it lives here during traversal so
+  // that it does not occupy registers across the hot loop (the kernel runs at the 128-VGPR edge of 4 waves per SIMD).
+  __shared__ uint4 lds_rng[2][RBLOCK];
   uint32_t* const lds_stack = reinterpret_cast<uint32_t*>(lds_raw);
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -66,7 +72,6 @@ __global__ void __launch_bounds__(RBLOCK, MIRT_WAVES_PER_SIMD) trace_kernel(cons
   // takes the next chunk from a global counter whenever its local one is used up (one atomic per chunk), so waves that
   // draw cheap samples simply draw more of them -- this is what keeps the tail short when a GPU renders only a stripe set.
   unsigned long long c_next = 0, c_end = 0;   // wave-uniform: this wave's current chunk
-  const unsigned long long nchunks = ((unsigned long long)h.num_samples + WORK_CHUNK - 1) / WORK_CHUNK;
   bool exhausted = false;                      // wave-uniform: the global counter has run past the frame
 
   Lane S;
@@ -82,6 +87,8 @@ __global__ void __launch_bounds__(RBLOCK, MIRT_WAVES_PER_SIMD) trace_kernel(cons
   S.tplane = INFINITY; S.plane_id = -1;
   S.cur = REF_NONE; S.tos = REF_NONE; S.sp = 0; S.tbest = INFINITY; S.refbest = REF_NONE;
 
+  lds_rng[0][tid] = make_uint4(0, 0, 0, 0);
+  lds_rng[1][tid] = make_uint4(0, 0, 0, 0);
   for (;;) {
     // ================= shade / refill phase: lanes that are not traversing =================
     unsigned long long pf_a = 0;
@@ -91,6 +98,11 @@ __global__ void __launch_bounds__(RBLOCK, MIRT_WAVES_PER_SIMD) trace_kernel(cons
     const RenderArgs* aq = ap;
     asm volatile("" : "+s"(aq));
     const RenderArgs& a = *aq;
+    {
+      const uint4 r0 = lds_rng[0][tid], r1 = lds_rng[1][tid];
+      S.rng.v0 = r0.x; S.rng.v1 = r0.y; S.rng.v2 = r0.z; S.rng.v3 = r0.w;
+      S.rng.v4 = r1.x; S.rng.d = r1.y; S.rng.bm_extra = __uint_as_float(r1.z); S.rng.bm_flag = (int)r1.w;
+    }
     while (!S.trav && S.g >= 0) {
       if (S.batch_pending) batch_next<COUNT>(a, S, cn);
       else advance<COUNT>(a, S, cn, gid, gthreads);
@@ -99,6 +111,8 @@ __global__ void __launch_bounds__(RBLOCK, MIRT_WAVES_PER_SIMD) trace_kernel(cons
       const unsigned long long need = __ballot(!S.trav && S.g < 0);
       if (need) {
         const int want = __popcll(need);
+        const unsigned long long nsamples = (unsigned long long)a.num_samples;
+        const unsigned long long nchunks = (nsamples + WORK_CHUNK - 1) / WORK_CHUNK;
         const int r = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(need >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)need, 0u));
         int given = 0;
         long long my = -1;
@@ -106,14 +120,14 @@ __global__ void __launch_bounds__(RBLOCK, MIRT_WAVES_PER_SIMD) trace_kernel(cons
           if (c_next >= c_end) {
             unsigned long long k = 0;
             if (lane == 0) {
-              k = atomicAdd(h.work_counter, 1ull);
+              k = atomicAdd(a.work_counter, 1ull);
               // longest-first hand-out order measured on an earlier frame (any order gives the same pixels)
-              if (k < nchunks && h.chunk_order) k = h.chunk_order[k];
+              if (k < nchunks && a.chunk_order) k = a.chunk_order[k];
             }
             k = __shfl(k, 0);
             if (k >= nchunks) { exhausted = true; break; }
             c_next = k * WORK_CHUNK;
-            c_end = (c_next + WORK_CHUNK < (unsigned long long)h.num_samples) ? c_next + WORK_CHUNK : (unsigned long long)h.num_samples;
+            c_end = (c_next + WORK_CHUNK < nsamples) ? c_next + WORK_CHUNK : nsamples;
           }
           const int avail = (int)(c_end - c_next);
           const int take = (want - given < avail) ? want - given : avail;
@@ -124,6 +138,8 @@ __global__ void __launch_bounds__(RBLOCK, MIRT_WAVES_PER_SIMD) trace_kernel(cons
         if (my >= 0) init_sample<COUNT>(a, S, cn, my);
       }
     }
+    lds_rng[0][tid] = make_uint4(S.rng.v0, S.rng.v1, S.rng.v2, S.rng.v3);
+    lds_rng[1][tid] = make_uint4(S.rng.v4, S.rng.d, __float_as_uint(S.rng.bm_extra), (uint32_t)S.rng.bm_flag);
     if (__ballot(S.trav) == 0) {
       if (exhausted && __ballot(S.g >= 0) == 0) break;
       continue;
@@ -174,10 +190,16 @@ __global__ void __launch_bounds__(RBLOCK, MIRT_WAVES_PER_SIMD) trace_kernel(cons
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       }
 #endif
-      if (S.trav) {
+      // A wave executes the node path and the primitive path one after the other whenever its lanes are split between
+      // them, and with ~45 live lanes nearly every iteration has a lane or two at a primitive.  So lanes that reach a
+      // primitive wait until leaf_k of them have one pending (or nothing else is left to do): the primitive code then
+      // runs in a fraction of the iterations.  Each ray still performs exactly the same sequence of steps.
+      const bool leaf = S.trav && (S.cur & REF_LEAF) != 0;
+      const unsigned long long lm = __ballot(leaf);
+      const bool do_leaf = __popcll(lm) >= h.leaf_k || __ballot(S.trav && !leaf) == 0 || drain;
+      if (S.trav && (!leaf || do_leaf)) {
         ++S.steps;
         // one fetch per iteration: the record `cur` names -- a node (4 x 16 B) or a primitive (sphere 16 B, triangle 48 B)
-        const bool leaf = (S.cur & REF_LEAF) != 0;
         const bool tri = leaf && (S.cur & REF_TRI);
 #if MIRT_QUAD_FETCH
         const float4* rec = reinterpret_cast<const float4*>(stage + (lane & 3) * STAGE_ROUND_BYTES + (lane & ~3) * 16);
@@ -189,8 +211,18 @@ __global__ void __launch_bounds__(RBLOCK, MIRT_WAVES_PER_SIMD) trace_kernel(cons
         const float4* rec = reinterpret_cast<const float4*>(heap + roff);
         const float4 q0 = rec[0];
         float4 q1 = make_float4(0, 0, 0, 0), q2 = q1, q3 = q1;
+#if MIRT_EARLY_CHILD
+        if (!leaf || tri) {
+          q1 = rec[1]; q2 = rec[2];
+          if (!leaf) { const float2 ch = *reinterpret_cast<const float2*>(rec + 3); q3.x = ch.x; q3.y = ch.y; }
+          // keeps the child-reference load up here with the other quarters (one wait for the whole record); measured
+          // slower than letting the compiler sink it behind the box tests (55.4 vs 47.6 ms), so off by default
+          asm volatile("" : "+v"(q3.x), "+v"(q3.y));
+        }
+#else
         if (!leaf || tri) { q1 = rec[1]; q2 = rec[2]; }
         if (!leaf) q3 = rec[3];
+#endif
 #endif
         bool pop = false;
         if (leaf) {
@@ -297,7 +329,8 @@ __global__ void __launch_bounds__(RBLOCK, MIRT_WAVES_PER_SIMD) trace_kernel(cons
   }
   (void)pf_node;
 
-  if (COUNT && h.counters) {
+  unsigned long long* const counters = COUNT ? ap->counters : nullptr;
+  if (COUNT && counters) {
     uint32_t v[8] = {cn.samples, cn.rays, cn.shadow_rays, cn.internal_visits, cn.sphere_tests, cn.tri_tests, cn.mat_fetches, cn.max_stack};
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
@@ -305,11 +338,11 @@ __global__ void __launch_bounds__(RBLOCK, MIRT_WAVES_PER_SIMD) trace_kernel(cons
       if (k == 7) {
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) { unsigned long long y = __shfl_xor(x, off); x = x > y ? x : y; }
-        if ((tid & 63) == 0) atomicMax(&h.counters[k], x);
+        if ((tid & 63) == 0) atomicMax(&counters[k], x);
       } else {
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) x += __shfl_xor(x, off);
-        if ((tid & 63) == 0) atomicAdd(&h.counters[k], x);
+        if ((tid & 63) == 0) atomicAdd(&counters[k], x);
       }
     }
   }
@@ -637,7 +670,9 @@ int render(MirtScene* sc, const MirtRenderParams* p, void* d_rgba8, void* d_rgba
     h.nodes = a.nodes; h.sph_base = a.sph_base; h.tri_base = a.tri_base; h.root_ref = a.root_ref;
     h.planes = a.planes; h.num_planes = a.num_planes; h.suns = a.suns; h.num_suns = a.num_suns; h.bulbs = a.bulbs; h.num_bulbs = a.num_bulbs;
     h.stack_spill = a.stack_spill; h.lds_depth = a.lds_depth; h.refill_k = a.refill_k; h.batch_k = a.batch_k; h.drain_lanes = a.drain_lanes;
-    h.num_samples = a.num_samples; h.work_counter = a.work_counter; h.chunk_order = a.chunk_order; h.counters = a.counters; h.prof = nullptr;
+    h.leaf_k = 8;
+    if (const char* e = getenv("MIRT_LEAF_K")) { int k = atoi(e); if (k >= 1 && k <= 64) h.leaf_k = k; }
+    h.prof = nullptr;
     if (!cx.args_dev) MIRT_HIP(hipMalloc(&cx.args_dev, sizeof(RenderArgs)));
     if (prof) {
       if (!cx.prof) MIRT_HIP(hipMalloc(&cx.prof, 16 * sizeof(unsigned long long)));

@@ -78,10 +78,7 @@ struct HotArgs {
   const LightDev* bulbs; int num_bulbs;
   uint32_t* stack_spill;
   int lds_depth, refill_k, batch_k, drain_lanes;
-  long long num_samples;
-  unsigned long long* work_counter;
-  const uint32_t* chunk_order;
-  unsigned long long* counters;
+  int leaf_k;                     // primitive tests are held back until this many lanes of the wave have one pending
   unsigned long long* prof;
 };
 
