@@ -302,11 +302,12 @@ __global__ void __launch_bounds__(BLOCK) karras_kernel(const uint32_t* __restric
   if (i == 0) parent[0] = -1;
 }
 
-MIRT_DEV uint32_t make_ref(uint32_t node, uint32_t leaf_base, const uint32_t* __restrict__ order, const MirtPrimRef* __restrict__ refs)
+MIRT_DEV uint32_t make_ref(uint32_t node, uint32_t leaf_base, const uint32_t* __restrict__ order, const MirtPrimRef* __restrict__ refs,
+                           uint32_t sph_base16, uint32_t tri_base16)
 {
-  if (node < leaf_base) return node;
+  if (node < leaf_base) return 4u * node;
   const MirtPrimRef r = refs[order[node - leaf_base]];
-  return REF_LEAF | (r.type ? REF_TRI : 0u) | (r.id & REF_IDMASK);
+  return r.type ? (REF_LEAF | REF_TRI | (tri_base16 + 3u * r.id)) : (REF_LEAF | (sph_base16 + r.id));
 }
 
 // set_aabb_kernel_adapted, lbvh_builder.cu:324-387.  One thread per leaf; the second thread to arrive at a parent
@@ -316,7 +317,7 @@ __global__ void __launch_bounds__(BLOCK) refit_pack_kernel(int n, const uint32_t
                                                            const float4* __restrict__ spheres, const float4* __restrict__ tri_verts,
                                                            const uint32_t* __restrict__ child_l, const uint32_t* __restrict__ child_r,
                                                            const int* __restrict__ parent, uint32_t* __restrict__ arrived,
-                                                           float* boxes, float4* __restrict__ nodes)
+                                                           float* boxes, float4* __restrict__ nodes, uint32_t sph_base16, uint32_t tri_base16)
 {
   const int j = blockIdx.x * BLOCK + threadIdx.x;
   if (j >= n) return;
@@ -346,12 +347,13 @@ __global__ void __launch_bounds__(BLOCK) refit_pack_kernel(int n, const uint32_t
     const float c0 = __hip_atomic_load(c + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), c1 = __hip_atomic_load(c + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const float c2 = __hip_atomic_load(c + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), c3 = __hip_atomic_load(c + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const float c4 = __hip_atomic_load(c + 4, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), c5 = __hip_atomic_load(c + 5, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    // traversal record: child boxes as (min xyz, max xyz) pairs + child references
+    // traversal record: both child boxes as (min, max) pairs per axis (the slab test works on pairs) + child references
     float4* rec = nodes + 4 * (size_t)p;
-    rec[0] = make_float4(a0, a2, a4, a1);
-    rec[1] = make_float4(a3, a5, c0, c2);
-    rec[2] = make_float4(c4, c1, c3, c5);
-    rec[3] = make_float4(__uint_as_float(make_ref(lc, leaf_base, order, refs)), __uint_as_float(make_ref(rc, leaf_base, order, refs)), 0.0f, 0.0f);
+    rec[0] = make_float4(a0, a1, a2, a3);
+    rec[1] = make_float4(a4, a5, c0, c1);
+    rec[2] = make_float4(c2, c3, c4, c5);
+    rec[3] = make_float4(__uint_as_float(make_ref(lc, leaf_base, order, refs, sph_base16, tri_base16)),
+                         __uint_as_float(make_ref(rc, leaf_base, order, refs, sph_base16, tri_base16)), 0.0f, 0.0f);
     // AABB(AABB, AABB), interval.cuh:83-88
     float* pb = boxes + 6 * (size_t)p;
     __hip_atomic_store(pb + 0, fminf(a0, c0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); __hip_atomic_store(pb + 1, fmaxf(a1, c1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -410,7 +412,7 @@ int build_lbvh(MirtScene* sc, hipStream_t stream)
     MIRT_HIP(hipMemsetAsync(sc->parent, 0xff, sizeof(int), stream));
   }
   hipLaunchKernelGGL(refit_pack_kernel, dim3(nblk), dim3(BLOCK), 0, stream, n, sc->order, sc->refs_in, sc->spheres, sc->tri_verts,
-                     sc->child_l, sc->child_r, sc->parent, arrived, sc->boxes, sc->nodes);
+                     sc->child_l, sc->child_r, sc->parent, arrived, sc->boxes, sc->nodes, sc->sph_base / 16u, sc->tri_base / 16u);
   MIRT_HIP(hipGetLastError());
   MIRT_HIP(hipEventRecord(sc->ev1, stream));
   MIRT_HIP(hipStreamSynchronize(stream));   // lbvh_builder.cu:475
@@ -421,7 +423,7 @@ int build_lbvh(MirtScene* sc, hipStream_t stream)
     MIRT_HIP(hipMemcpy(&ord, sc->order, 4, hipMemcpyDeviceToHost));
     MirtPrimRef r;
     MIRT_HIP(hipMemcpy(&r, sc->refs_in + ord, sizeof(r), hipMemcpyDeviceToHost));
-    sc->root_ref = REF_LEAF | (r.type ? REF_TRI : 0u) | (r.id & REF_IDMASK);
+    sc->root_ref = r.type ? (REF_LEAF | REF_TRI | (sc->tri_base / 16u + 3u * r.id)) : (REF_LEAF | (sc->sph_base / 16u + r.id));
   } else {
     sc->root_ref = 0;
   }

@@ -174,8 +174,7 @@ __global__ void __launch_bounds__(RBLOCK, MIRT_WAVES_PER_SIMD) trace_kernel(cons
       {
         uint32_t off = 0xffffffffu;
         if (S.trav) {
-          const uint32_t id0 = S.cur & REF_IDMASK;
-          off = (S.cur & REF_LEAF) ? ((S.cur & REF_TRI) ? h.tri_base + 48u * id0 : h.sph_base + 16u * id0) : 64u * S.cur;
+          off = S.cur << 4;
         }
         const uint32_t sub = (uint32_t)(lane & 3) * 16u;
 #define MIRT_FETCH_ROUND(j)                                                                                                    \
@@ -206,8 +205,7 @@ __global__ void __launch_bounds__(RBLOCK, MIRT_WAVES_PER_SIMD) trace_kernel(cons
         const float4 q0 = rec[0], q1 = rec[1], q2 = rec[2], q3 = rec[3];
 #else
         // one base pointer (the record heap) + a 32-bit byte offset: scalar base, 32-bit vector offset loads
-        const uint32_t id = S.cur & REF_IDMASK;
-        const uint32_t roff = leaf ? (tri ? h.tri_base + 48u * id : h.sph_base + 16u * id) : 64u * S.cur;
+        const uint32_t roff = S.cur << 4;
         const float4* rec = reinterpret_cast<const float4*>(heap + roff);
         const float4 q0 = rec[0];
         float4 q1 = make_float4(0, 0, 0, 0), q2 = q1, q3 = q1;
@@ -271,18 +269,8 @@ __global__ void __launch_bounds__(RBLOCK, MIRT_WAVES_PER_SIMD) trace_kernel(cons
         } else {
           if (COUNT) cn.internal_visits++;
           // hit_aabb_adapted, bvh_traversal.cu:11-44, on both children
-          float tx1 = (q0.x - S.o.x) * S.inv.x, tx2 = (q0.w - S.o.x) * S.inv.x;
-          float ty1 = (q0.y - S.o.y) * S.inv.y, ty2 = (q1.x - S.o.y) * S.inv.y;
-          float tz1 = (q0.z - S.o.z) * S.inv.z, tz2 = (q1.y - S.o.z) * S.inv.z;
-          float te = fmaxf(fmaxf(fminf(tx1, tx2), fminf(ty1, ty2)), fminf(tz1, tz2));
-          float tx = fminf(fminf(fmaxf(tx1, tx2), fmaxf(ty1, ty2)), fmaxf(tz1, tz2));
-          const bool hl = te < tx && te < S.tbest && tx > tmin;
-          tx1 = (q1.z - S.o.x) * S.inv.x; tx2 = (q2.y - S.o.x) * S.inv.x;
-          ty1 = (q1.w - S.o.y) * S.inv.y; ty2 = (q2.z - S.o.y) * S.inv.y;
-          tz1 = (q2.x - S.o.z) * S.inv.z; tz2 = (q2.w - S.o.z) * S.inv.z;
-          te = fmaxf(fmaxf(fminf(tx1, tx2), fminf(ty1, ty2)), fminf(tz1, tz2));
-          tx = fminf(fminf(fmaxf(tx1, tx2), fmaxf(ty1, ty2)), fmaxf(tz1, tz2));
-          const bool hr = te < tx && te < S.tbest && tx > tmin;
+          bool hl, hr;
+          box_pair(q0, q1, q2, S.o.x, S.o.y, S.o.z, S.inv.x, S.inv.y, S.inv.z, S.tbest, tmin, hl, hr);
           const uint32_t lref = __float_as_uint(q3.x), rref = __float_as_uint(q3.y);
           if (hl && hr) {
             S.cur = lref;
@@ -667,7 +655,7 @@ int render(MirtScene* sc, const MirtRenderParams* p, void* d_rgba8, void* d_rgba
     cx.wf_trace_ms = tms;
   } else {
     HotArgs h;
-    h.nodes = a.nodes; h.sph_base = a.sph_base; h.tri_base = a.tri_base; h.root_ref = a.root_ref;
+    h.nodes = a.nodes; h.root_ref = a.root_ref;
     h.planes = a.planes; h.num_planes = a.num_planes; h.suns = a.suns; h.num_suns = a.num_suns; h.bulbs = a.bulbs; h.num_bulbs = a.num_bulbs;
     h.stack_spill = a.stack_spill; h.lds_depth = a.lds_depth; h.refill_k = a.refill_k; h.batch_k = a.batch_k; h.drain_lanes = a.drain_lanes;
     h.leaf_k = 8;

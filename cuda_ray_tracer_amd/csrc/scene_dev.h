@@ -12,12 +12,13 @@
 
 namespace mirt {
 
-// child reference inside a packed node / the root reference
-//   bit 31 = leaf; leaf: bit 30 = primitive type (0 sphere, 1 triangle), bits 0..29 = index in its array
-//   internal: index of the internal node
+// child reference inside a packed node / the root reference: names a record of the heap [nodes | spheres | triangles]
+//   bit 31 = leaf (a primitive record); bit 30 = primitive type (0 sphere, 1 triangle);
+//   bits 0..27 = the record's offset in the heap in 16-byte units (node i: 4 i; sphere k: sph_base/16 + k; triangle k:
+//   tri_base/16 + 3 k), so that the traversal step gets a record's byte offset with one shift
 constexpr uint32_t REF_LEAF = 0x80000000u;
 constexpr uint32_t REF_TRI = 0x40000000u;
-constexpr uint32_t REF_IDMASK = 0x3fffffffu;
+constexpr uint32_t REF_OFFMASK = 0x0fffffffu;  // the record's offset in the heap, in 16-byte units: `ref << 4` is its byte offset (the shift drops the flags)
 constexpr uint32_t REF_NONE = 0xffffffffu;   // empty scene / plane marker is separate
 
 struct PlaneDev { float nx, ny, nz, px, py, pz; float mat[11]; float pad; };   // 72 B
@@ -72,7 +73,7 @@ struct RenderArgs {
 // scalar registers across the hot loop.
 struct HotArgs {
   const float4* nodes;            // start of the record heap
-  uint32_t sph_base, tri_base, root_ref;
+  uint32_t root_ref;
   const PlaneDev* planes; int num_planes;
   const LightDev* suns; int num_suns;
   const LightDev* bulbs; int num_bulbs;

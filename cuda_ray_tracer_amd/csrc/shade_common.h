@@ -105,6 +105,25 @@ MIRT_DEV f3 rough_normal(const f3& n, float roughness, Xorwow& rng)
   return n + mk3(a, b, c);
 }
 
+// hit_aabb_adapted, bvh_traversal.cu:11-44, on both child boxes of a node record (q0..q2: six (min, max) pairs).  Written
+// on 2-vectors so that the subtract/multiply of a pair is one packed instruction (v_pk_add_f32 / v_pk_mul_f32); every
+// lane value is the same single-rounded (plane - origin) * inv_dir product as in the scalar form.
+typedef float v2f __attribute__((ext_vector_type(2)));
+MIRT_DEV void box_pair(const float4 q0, const float4 q1, const float4 q2, float o_x, float o_y, float o_z, float i_x, float i_y, float i_z,
+                       float tbest, float tmin, bool& hl, bool& hr)
+{
+  const v2f ox = {o_x, o_x}, oy = {o_y, o_y}, oz = {o_z, o_z};
+  const v2f ix = {i_x, i_x}, iy = {i_y, i_y}, iz = {i_z, i_z};
+  const v2f lx = (v2f{q0.x, q0.y} - ox) * ix, ly = (v2f{q0.z, q0.w} - oy) * iy, lz = (v2f{q1.x, q1.y} - oz) * iz;
+  const v2f rx = (v2f{q1.z, q1.w} - ox) * ix, ry = (v2f{q2.x, q2.y} - oy) * iy, rz = (v2f{q2.z, q2.w} - oz) * iz;
+  float te = fmaxf(fmaxf(fminf(lx.x, lx.y), fminf(ly.x, ly.y)), fminf(lz.x, lz.y));
+  float tx = fminf(fminf(fmaxf(lx.x, lx.y), fmaxf(ly.x, ly.y)), fmaxf(lz.x, lz.y));
+  hl = te < tx && te < tbest && tx > tmin;
+  te = fmaxf(fmaxf(fminf(rx.x, rx.y), fminf(ry.x, ry.y)), fminf(rz.x, rz.y));
+  tx = fminf(fminf(fmaxf(rx.x, rx.y), fmaxf(ry.x, ry.y)), fmaxf(rz.x, rz.y));
+  hr = te < tx && te < tbest && tx > tmin;
+}
+
 struct Counters { uint32_t samples, rays, shadow_rays, internal_visits, sphere_tests, tri_tests, mat_fetches, max_stack; };
 
 // Everything a lane carries from one loop iteration to the next.
@@ -253,7 +272,8 @@ MIRT_DEV int advance_core(const RenderArgs& a, Lane& S, Counters& cn, const long
     Mat nm;
     nm.color = mk3(0, 0, 0); nm.shininess = mk3(0, 0, 0); nm.trans = mk3(0, 0, 0); nm.ior = 1.458f; nm.roughness = 0.0f;
     if (use_bvh) {
-      const uint32_t id = S.refbest & REF_IDMASK;
+      const uint32_t off16 = S.refbest & REF_OFFMASK;
+      const uint32_t id = (S.refbest & REF_TRI) ? (off16 - a.tri_base / 16u) / 3u : off16 - a.sph_base / 16u;
       Np = S.tbest * rd0 + ro0;
       if (S.refbest & REF_TRI) {
         const float4 q0 = a.tris[3 * (size_t)id + 0], q1 = a.tris[3 * (size_t)id + 1];

@@ -354,8 +354,7 @@ __global__ void __launch_bounds__(WBLOCK, MIRT_WF_WAVES_PER_SIMD) wf_trace_kerne
     {
       uint32_t off = 0xffffffffu;
       if (trav) {
-        const uint32_t id0 = cur & REF_IDMASK;
-        off = (cur & REF_LEAF) ? ((cur & REF_TRI) ? a.tri_base + 48u * id0 : a.sph_base + 16u * id0) : 64u * cur;
+        off = cur << 4;
       }
       quad_fetch(reinterpret_cast<const unsigned char*>(a.nodes), off, lane, q0, q1, q2, q3);
     }
@@ -364,8 +363,7 @@ __global__ void __launch_bounds__(WBLOCK, MIRT_WF_WAVES_PER_SIMD) wf_trace_kerne
       const bool leaf = (cur & REF_LEAF) != 0;
       const bool tri = leaf && (cur & REF_TRI);
 #if !MIRT_WF_QUAD_FETCH
-      const uint32_t id = cur & REF_IDMASK;
-      const uint32_t roff = leaf ? (tri ? a.tri_base + 48u * id : a.sph_base + 16u * id) : 64u * cur;
+      const uint32_t roff = cur << 4;
       const float4* rec = reinterpret_cast<const float4*>(reinterpret_cast<const unsigned char*>(a.nodes) + roff);
       const float4 q0 = rec[0];
       float4 q1 = make_float4(0, 0, 0, 0), q2 = q1, q3 = q1;
@@ -419,18 +417,8 @@ __global__ void __launch_bounds__(WBLOCK, MIRT_WF_WAVES_PER_SIMD) wf_trace_kerne
       } else {
         if (COUNT) cn.internal_visits++;
         // hit_aabb_adapted, bvh_traversal.cu:11-44, on both children
-        float tx1 = (q0.x - o.x) * inv.x, tx2 = (q0.w - o.x) * inv.x;
-        float ty1 = (q0.y - o.y) * inv.y, ty2 = (q1.x - o.y) * inv.y;
-        float tz1 = (q0.z - o.z) * inv.z, tz2 = (q1.y - o.z) * inv.z;
-        float te = fmaxf(fmaxf(fminf(tx1, tx2), fminf(ty1, ty2)), fminf(tz1, tz2));
-        float tx = fminf(fminf(fmaxf(tx1, tx2), fmaxf(ty1, ty2)), fmaxf(tz1, tz2));
-        const bool hl = te < tx && te < tbest && tx > tmin;
-        tx1 = (q1.z - o.x) * inv.x; tx2 = (q2.y - o.x) * inv.x;
-        ty1 = (q1.w - o.y) * inv.y; ty2 = (q2.z - o.y) * inv.y;
-        tz1 = (q2.x - o.z) * inv.z; tz2 = (q2.w - o.z) * inv.z;
-        te = fmaxf(fmaxf(fminf(tx1, tx2), fminf(ty1, ty2)), fminf(tz1, tz2));
-        tx = fminf(fminf(fmaxf(tx1, tx2), fmaxf(ty1, ty2)), fmaxf(tz1, tz2));
-        const bool hr = te < tx && te < tbest && tx > tmin;
+        bool hl, hr;
+        box_pair(q0, q1, q2, o.x, o.y, o.z, inv.x, inv.y, inv.z, tbest, tmin, hl, hr);
         const uint32_t lref = __float_as_uint(q3.x), rref = __float_as_uint(q3.y);
         if (hl && hr) {
           cur = lref;
