@@ -200,32 +200,38 @@ MIRT_DEV void batch_next(const Args& a, Lane& S, Counters& cn)
     if (occluded) S.occl |= 1ull << S.li;
   }
   ++S.li;
+  // the lanes of a wave are at different rays of their batches: each kind only sets the ray up, and all of them share
+  // one start_ray (one copy of the plane loop instead of three executed one after the other)
+  bool go = true;
   if (S.li < nlights) {
     // shadow ray, draw.cu:346 / 362-363
+    S.o = S.bo;
+    S.limit = INFINITY;
     S.shadow = true;
+    S.bounce = 1;
     if (S.li < a.num_suns) {
       // direction and its reciprocal are per-light constants (host-computed, same arithmetic)
       const LightDev& lt = a.suns[S.li];
-      S.o = S.bo; S.d = mk3(lt.nx, lt.ny, lt.nz); S.inv = mk3(lt.ix, lt.iy, lt.iz); S.bounce = 1;
-      S.limit = INFINITY;
-      start_ray<COUNT, true>(a, S, cn);
+      S.d = mk3(lt.nx, lt.ny, lt.nz); S.inv = mk3(lt.ix, lt.iy, lt.iz);
     } else {
       const LightDev& lt = a.bulbs[S.li - a.num_suns];
       const f3 bd = mk3(lt.x, lt.y, lt.z) - S.Hp;
-      set_ray(S, mkray(S.bo, bd, 1));
+      S.d = mkray(S.bo, bd, 1).d;
+      S.inv = mk3(1.0f / S.d.x, 1.0f / S.d.y, 1.0f / S.d.z);
       S.limit = length(bd);
-      start_ray<COUNT>(a, S, cn);
     }
   } else if (S.li == nlights && S.has_reflect) {
     S.o = S.bo; S.d = S.rdir; S.bounce = S.Hbounce - 1;
-    S.shadow = false;
+    S.inv = mk3(1.0f / S.d.x, 1.0f / S.d.y, 1.0f / S.d.z);
     S.limit = INFINITY;
-    start_ray<COUNT>(a, S, cn);
+    S.shadow = false;
   } else {
+    go = false;
     S.batch_pending = false;
     S.shadow = false;
     S.trav = false;
   }
+  if (go) start_ray<COUNT, true>(a, S, cn);
 }
 
 // Consume the finished trace of lane S and run its shading state machine until it either has the next ray(s) or the
