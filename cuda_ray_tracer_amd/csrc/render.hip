@@ -38,22 +38,13 @@ constexpr int DRAIN_LANES = 16;       // a wave with this few live lanes (and no
 #define MIRT_STACK_LDS 32
 #endif
 constexpr int STACK_LDS = MIRT_STACK_LDS;
-#ifndef MIRT_EARLY_CHILD
-#define MIRT_EARLY_CHILD 0
-#endif
-#ifndef MIRT_QUAD_FETCH
-#define MIRT_QUAD_FETCH 0   // measured on MI355X: 77.5 ms vs 68.1 ms without (the LDS round trip adds latency; TA is not the limiter)
-#endif
-constexpr int STAGE_ROUND_BYTES = 64 * 16 + 16;          // +16: rounds land on different LDS bank phases (conflict-free ds_read_b128)
-constexpr int STAGE_WAVE_BYTES = MIRT_QUAD_FETCH ? 4 * STAGE_ROUND_BYTES : 0;
 template <bool COUNT, bool PROF>
 __global__ void __launch_bounds__(RBLOCK, MIRT_WAVES_PER_SIMD) trace_kernel(const RenderArgs* __restrict__ ap, const HotArgs h)
 {
   // PROF: diagnostic build only -- cycle stamps per phase, written to h.prof (never used for timing claims)
   unsigned long long pf_S = 0, pf_T = 0, pf_iters = 0, pf_active = 0, pf_Sent = 0, pf_Slanes = 0, pf_Bent = 0, pf_Blanes = 0, pf_leaf = 0, pf_node = 0;
   const unsigned long long pf_t0 = PROF ? clock64() : 0;
-  // One LDS array: [traversal stacks: STACK_LDS x RBLOCK words][per-wave record staging: 4 rounds x (64 x 16 B + 16 B pad)]
-  __shared__ __attribute__((aligned(16))) unsigned char lds_raw[STACK_LDS * RBLOCK * 4 + (RBLOCK / 64) * STAGE_WAVE_BYTES];
+  __shared__ __attribute__((aligned(16))) unsigned char lds_raw[STACK_LDS * RBLOCK * 4];     // traversal stacks: STACK_LDS x RBLOCK words
   // The random-number state (8 words per lane) is only touched in the shade phase: it lives here during traversal so
   // that it does not occupy registers across the hot loop (the kernel runs at the 128-VGPR edge of 4 waves per SIMD).
   __shared__ uint4 lds_rng[2][RBLOCK];
@@ -61,9 +52,7 @@ __global__ void __launch_bounds__(RBLOCK, MIRT_WAVES_PER_SIMD) trace_kernel(cons
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   (void)lane;
-  unsigned char* const stage = lds_raw + STACK_LDS * RBLOCK * 4 + __builtin_amdgcn_readfirstlane(tid >> 6) * STAGE_WAVE_BYTES;
   const unsigned char* const heap = reinterpret_cast<const unsigned char*>(h.nodes);
-  (void)stage;
   const long long gid = (long long)blockIdx.x * RBLOCK + tid;
   const long long gthreads = (long long)gridDim.x * RBLOCK;
   Counters cn = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -167,28 +156,6 @@ __global__ void __launch_bounds__(RBLOCK, MIRT_WAVES_PER_SIMD) trace_kernel(cons
         if (!S.trav && S.batch_pending) batch_next<COUNT>(h, S, cn);
       }
       if (PROF) { pf_iters++; pf_active += __popcll(__ballot(S.trav)); pf_leaf += __popcll(__ballot(S.trav && (S.cur & REF_LEAF))); }
-#if MIRT_QUAD_FETCH
-      // Record fetch, cooperative over quads: in round j the four lanes of a quad bring the four 16-byte quarters of the
-      // record of quad-lane j's ray straight into LDS (one coalesced 64 B request instead of four divergent ones); each
-      // ray then reads its 64 bytes back with four conflict-free ds_read_b128.  All lanes take part (uniform control flow).
-      {
-        uint32_t off = 0xffffffffu;
-        if (S.trav) {
-          off = S.cur << 4;
-        }
-        const uint32_t sub = (uint32_t)(lane & 3) * 16u;
-#define MIRT_FETCH_ROUND(j)                                                                                                    \
-        {                                                                                                                      \
-          const uint32_t oj = (uint32_t)__builtin_amdgcn_mov_dpp((int)off, (j) | ((j) << 2) | ((j) << 4) | ((j) << 6), 0xf, 0xf, true); \
-          if (oj != 0xffffffffu)                                                                                               \
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(heap + oj + sub),                  \
-                                             (__attribute__((address_space(3))) void*)(stage + (j) * STAGE_ROUND_BYTES), 16, 0, 0); \
-        }
-        MIRT_FETCH_ROUND(0) MIRT_FETCH_ROUND(1) MIRT_FETCH_ROUND(2) MIRT_FETCH_ROUND(3)
-#undef MIRT_FETCH_ROUND
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      }
-#endif
       // A wave executes the node path and the primitive path one after the other whenever its lanes are split between
       // them, and with ~45 live lanes nearly every iteration has a lane or two at a primitive.  So lanes that reach a
       // primitive wait until leaf_k of them have one pending (or nothing else is left to do): the primitive code then
@@ -198,38 +165,20 @@ __global__ void __launch_bounds__(RBLOCK, MIRT_WAVES_PER_SIMD) trace_kernel(cons
       const bool do_leaf = __popcll(lm) >= h.leaf_k || __ballot(S.trav && !leaf) == 0 || drain;
       if (S.trav && (!leaf || do_leaf)) {
         ++S.steps;
-        // one fetch per iteration: the record `cur` names -- a node (4 x 16 B) or a primitive (sphere 16 B, triangle 48 B)
-        const bool tri = leaf && (S.cur & REF_TRI);
-#if MIRT_QUAD_FETCH
-        const float4* rec = reinterpret_cast<const float4*>(stage + (lane & 3) * STAGE_ROUND_BYTES + (lane & ~3) * 16);
-        const float4 q0 = rec[0], q1 = rec[1], q2 = rec[2], q3 = rec[3];
-#else
-        // one base pointer (the record heap) + a 32-bit byte offset: scalar base, 32-bit vector offset loads
-        const uint32_t roff = S.cur << 4;
-        const float4* rec = reinterpret_cast<const float4*>(heap + roff);
-        const float4 q0 = rec[0];
-        float4 q1 = make_float4(0, 0, 0, 0), q2 = q1, q3 = q1;
-#if MIRT_EARLY_CHILD
-        if (!leaf || tri) {
-          q1 = rec[1]; q2 = rec[2];
-          if (!leaf) { const float2 ch = *reinterpret_cast<const float2*>(rec + 3); q3.x = ch.x; q3.y = ch.y; }
-          // keeps the child-reference load up here with the other quarters (one wait for the whole record); measured
-          // slower than letting the compiler sink it behind the box tests (55.4 vs 47.6 ms), so off by default
-          asm volatile("" : "+v"(q3.x), "+v"(q3.y));
-        }
-#else
-        if (!leaf || tri) { q1 = rec[1]; q2 = rec[2]; }
-        if (!leaf) q3 = rec[3];
-#endif
-#endif
+        // one record per step: a node (64 B: two child boxes + two child references) or a primitive (sphere 16 B,
+        // triangle 48 B), addressed by one scalar base (the record heap) + a 32-bit byte offset.  Each kind loads the
+        // quarters it needs inside its own branch: no merged/zero-filled registers between the two paths.
+        const float4* rec = reinterpret_cast<const float4*>(heap + (S.cur << 4));
         bool pop = false;
         if (leaf) {
           // intersect_leaf_primitives, bvh_traversal.cu:47-89
           float t = 0.0f;
           bool hit = false;
-          if (tri) {
+          const float4 q0 = rec[0];
+          if (S.cur & REF_TRI) {
             // checkTriangleIntersectionSoA, struct.cu:111-163
             if (COUNT) cn.tri_tests++;
+            const float4 q1 = rec[1], q2 = rec[2];
             const f3 p0 = mk3(q0.x, q0.y, q0.z), nor = mk3(q0.w, q1.x, q1.y);
             const float denom = dot(S.d, nor);
             if (!(fabsf(denom) < 1e-9f)) {
@@ -269,20 +218,24 @@ __global__ void __launch_bounds__(RBLOCK, MIRT_WAVES_PER_SIMD) trace_kernel(cons
         } else {
           if (COUNT) cn.internal_visits++;
           // hit_aabb_adapted, bvh_traversal.cu:11-44, on both children
+          // (the empty asm keeps the compiler from merging this branch's first load with the primitive branch's and
+          // waiting for it before the other three are issued)
+          uint32_t noff = S.cur << 4;
+          asm volatile("" : "+v"(noff));
+          const float4* nrec = reinterpret_cast<const float4*>(heap + noff);
+          const float4 q0 = nrec[0], q1 = nrec[1], q2 = nrec[2];
+          const uint2 ch = *reinterpret_cast<const uint2*>(nrec + 3);
           bool hl, hr;
           box_pair(q0, q1, q2, S.o.x, S.o.y, S.o.z, S.inv.x, S.inv.y, S.inv.z, S.tbest, tmin, hl, hr);
-          const uint32_t lref = __float_as_uint(q3.x), rref = __float_as_uint(q3.y);
+          const uint32_t lref = ch.x, rref = ch.y;
           if (hl && hr) {
             S.cur = lref;
-            // push right: the previous top of stack goes to memory, the new top stays in a register
+            // push right: the previous top of stack goes to memory, the new top stays in a register.  With n entries
+            // on the stack, entry k < n sits in slot k and entry n is S.tos (slot 0 only ever receives the dead S.tos
+            // of an empty stack), so the slot to write is simply the current depth.
             if (S.sp < STACK_TOTAL) {
-              {
-                // the previous top goes to memory.  For an empty stack this writes a dead value to slot 0, which is
-                // rewritten before anything reads it -- one branch less in the hot loop.
-                const int slot = S.sp > 0 ? S.sp - 1 : 0;
-                if (slot < h.lds_depth) lds_stack[slot * RBLOCK + tid] = S.tos;
-                else h.stack_spill[(size_t)(slot - h.lds_depth) * gthreads + gid] = S.tos;
-              }
+              if (S.sp < h.lds_depth) lds_stack[S.sp * RBLOCK + tid] = S.tos;
+              else h.stack_spill[(size_t)(S.sp - h.lds_depth) * gthreads + gid] = S.tos;
               S.tos = rref;
               ++S.sp;
               if (COUNT) cn.max_stack = max(cn.max_stack, (uint32_t)S.sp);
@@ -296,12 +249,9 @@ __global__ void __launch_bounds__(RBLOCK, MIRT_WAVES_PER_SIMD) trace_kernel(cons
           else {
             S.cur = S.tos;
             --S.sp;
-            {
-              // reload the new top (a dead read of slot 0 when the stack is now empty)
-              const int slot = S.sp > 0 ? S.sp - 1 : 0;
-              S.tos = lds_stack[(slot < h.lds_depth ? slot : 0) * RBLOCK + tid];
-              if (slot >= h.lds_depth) S.tos = h.stack_spill[(size_t)(slot - h.lds_depth) * gthreads + gid];
-            }
+            // reload the new top (a dead read of slot 0 when the stack is now empty)
+            S.tos = lds_stack[(S.sp < h.lds_depth ? S.sp : 0) * RBLOCK + tid];
+            if (S.sp >= h.lds_depth) S.tos = h.stack_spill[(size_t)(S.sp - h.lds_depth) * gthreads + gid];
           }
         }
       }
