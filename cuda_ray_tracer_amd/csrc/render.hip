@@ -296,6 +296,31 @@ MIRT_DEV unsigned char to_uchar_trunc(float f)
   return (unsigned char)f;
 }
 
+MIRT_DEV float4 mean_of(const float4 sum, int spp)
+{
+  const float inv = 1.0f / (float)spp;
+  return make_float4(sum.x * inv, sum.y * inv, sum.z * inv, sum.w * inv);
+}
+// pixel_color_accum / uchar conversion, draw.cu:191-205 (spp > 1) and draw.cu:120-135 (spp <= 1)
+MIRT_DEV void write_pixel(const ResolveArgs& a, long long lp, const float4 m)
+{
+  if (a.rgba_f32) a.rgba_f32[lp] = m;
+  uchar4 o;
+  if (a.spp <= 1) {
+    o.x = to_uchar_trunc(rgb_to_srgb(m.x) * 255);
+    o.y = to_uchar_trunc(rgb_to_srgb(m.y) * 255);
+    o.z = to_uchar_trunc(rgb_to_srgb(m.z) * 255);
+    o.w = to_uchar_trunc(m.w * 255);
+  } else {
+    o.x = to_uchar_round(rgb_to_srgb(m.x));
+    o.y = to_uchar_round(rgb_to_srgb(m.y));
+    o.z = to_uchar_round(rgb_to_srgb(m.z));
+    o.w = to_uchar_round(m.w);
+  }
+  reinterpret_cast<uchar4*>(a.rgba8)[lp] = o;
+}
+
+// spp <= 1, and the fallback for P > 64: one thread per pixel
 __global__ void __launch_bounds__(RBLOCK) resolve_kernel(const ResolveArgs a)
 {
   const long long lp = (long long)blockIdx.x * RBLOCK + threadIdx.x;
@@ -324,24 +349,32 @@ __global__ void __launch_bounds__(RBLOCK) resolve_kernel(const ResolveArgs a)
       }
       stk[top++] = x;
     }
-    const float4 sum = stk[0];
-    const float inv = 1.0f / (float)a.spp;
-    m = make_float4(sum.x * inv, sum.y * inv, sum.z * inv, sum.w * inv);
+    m = mean_of(stk[0], a.spp);
   }
-  if (a.rgba_f32) a.rgba_f32[lp] = m;
-  uchar4 o;
-  if (a.spp <= 1) {
-    o.x = to_uchar_trunc(rgb_to_srgb(m.x) * 255);
-    o.y = to_uchar_trunc(rgb_to_srgb(m.y) * 255);
-    o.z = to_uchar_trunc(rgb_to_srgb(m.z) * 255);
-    o.w = to_uchar_trunc(m.w * 255);
-  } else {
-    o.x = to_uchar_round(rgb_to_srgb(m.x));
-    o.y = to_uchar_round(rgb_to_srgb(m.y));
-    o.z = to_uchar_round(rgb_to_srgb(m.z));
-    o.w = to_uchar_round(m.w);
+  write_pixel(a, lp, m);
+}
+
+// The same sum for P <= 64 with one lane per sample: coalesced 16-byte loads, then literally the reference's butterfly
+// `for (mask = P/2; mask > 0; mask /= 2) v += shfl_xor(v, mask)` (draw.cu:181-189) inside each group of P lanes; the
+// group's lane 0 parks its sum in LDS and the first threads of the block finish the block's pixels (full waves in the
+// sRGB code instead of one lane in P).
+constexpr int TBLOCK = 1024;
+__global__ void __launch_bounds__(TBLOCK) resolve_tree_kernel(const ResolveArgs a, int P, int lg)
+{
+  __shared__ float4 sums[TBLOCK / 2];
+  const int tid = threadIdx.x;
+  const int ppb = TBLOCK >> lg;                       // pixels per block
+  const int si = tid & (P - 1);
+  const long long lp = (long long)blockIdx.x * ppb + (tid >> lg);
+  float4 v = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+  if (lp < a.num_local_pixels && si < a.spp) v = a.samples[lp * a.spp + si];
+  for (int mask = P >> 1; mask > 0; mask >>= 1) {
+    v.x += __shfl_xor(v.x, mask); v.y += __shfl_xor(v.y, mask); v.z += __shfl_xor(v.z, mask); v.w += __shfl_xor(v.w, mask);
   }
-  reinterpret_cast<uchar4*>(a.rgba8)[lp] = o;
+  if (si == 0) sums[tid >> lg] = v;
+  __syncthreads();
+  const long long lq = (long long)blockIdx.x * ppb + tid;
+  if (tid < ppb && lq < a.num_local_pixels) write_pixel(a, lq, mean_of(sums[tid], a.spp));
 }
 
 __global__ void __launch_bounds__(RBLOCK) scatter_kernel(const uchar4* __restrict__ part, uchar4* __restrict__ frame, long long n,
@@ -391,31 +424,50 @@ __global__ void probe_xorwow_kernel(RngTablesDev t, int spp, int nstreams, int d
 // ---- longest-first scheduling: order the frame's chunks by the cost measured on a previous frame ------------------------
 constexpr int SORT_BINS = 1024;
 MIRT_DEV uint32_t cost_bin(uint32_t c) { const uint32_t b = c >> 3; return b < (uint32_t)SORT_BINS ? (uint32_t)(SORT_BINS - 1) - b : 0u; }   // bin 0 = most expensive
-__global__ void __launch_bounds__(RBLOCK) order_hist_kernel(const uint32_t* __restrict__ cost, uint32_t n, uint32_t* __restrict__ bins)
+// One block: the per-bin counters are LDS atomics (global atomics on a handful of hot bins -- half the frame is sky --
+// ran at ~90 per microsecond), and each thread walks a contiguous run of chunks and adds a run of equal bins at once.
+__global__ void __launch_bounds__(SORT_BINS) order_kernel(const uint32_t* __restrict__ cost, uint32_t n, uint32_t* __restrict__ order)
 {
-  const uint32_t i = blockIdx.x * RBLOCK + threadIdx.x;
-  if (i < n) atomicAdd(&bins[cost_bin(cost[i])], 1u);
-}
-__global__ void __launch_bounds__(SORT_BINS) order_scan_kernel(uint32_t* __restrict__ bins)
-{
-  __shared__ uint32_t s[SORT_BINS];
+  __shared__ uint32_t bins[SORT_BINS];
   const int t = threadIdx.x;
-  const uint32_t v = bins[t];
-  s[t] = v;
+  bins[t] = 0;
   __syncthreads();
+  const uint32_t per = (n + SORT_BINS - 1) / SORT_BINS;
+  const uint32_t lo = min(n, (uint32_t)t * per), hi = min(n, lo + per);
+  {
+    uint32_t cb = 0, cnt = 0;
+    for (uint32_t i = lo; i < hi; ++i) {
+      const uint32_t b = cost_bin(cost[i]);
+      if (cnt && b != cb) { atomicAdd(&bins[cb], cnt); cnt = 0; }
+      cb = b; ++cnt;
+    }
+    if (cnt) atomicAdd(&bins[cb], cnt);
+  }
+  __syncthreads();
+  const uint32_t own = bins[t];
   for (int o = 1; o < SORT_BINS; o <<= 1) {
-    const uint32_t x = (t >= o) ? s[t - o] : 0;
+    const uint32_t x = (t >= o) ? bins[t - o] : 0;
     __syncthreads();
-    s[t] += x;
+    bins[t] += x;
     __syncthreads();
   }
-  bins[t] = s[t] - v;
-}
-__global__ void __launch_bounds__(RBLOCK) order_scatter_kernel(const uint32_t* __restrict__ cost, uint32_t n, uint32_t* __restrict__ bins,
-                                                               uint32_t* __restrict__ order)
-{
-  const uint32_t i = blockIdx.x * RBLOCK + threadIdx.x;
-  if (i < n) order[atomicAdd(&bins[cost_bin(cost[i])], 1u)] = i;
+  const uint32_t excl = bins[t] - own;
+  __syncthreads();
+  bins[t] = excl;
+  __syncthreads();
+  {
+    uint32_t cb = 0, cnt = 0, first = lo;
+    for (uint32_t i = lo; i <= hi; ++i) {
+      const uint32_t b = (i < hi) ? cost_bin(cost[i]) : 0xffffffffu;
+      if (cnt && b != cb) {
+        const uint32_t base = atomicAdd(&bins[cb], cnt);
+        for (uint32_t k = 0; k < cnt; ++k) order[base + k] = first + k;
+        cnt = 0;
+      }
+      if (cnt == 0) first = i;
+      cb = b; ++cnt;
+    }
+  }
 }
 
 int64_t local_pixels(const MirtRenderParams* p)
@@ -635,7 +687,14 @@ int render(MirtScene* sc, const MirtRenderParams* p, void* d_rgba8, void* d_rgba
   ResolveArgs ra;
   ra.samples = cx.samples; ra.rgba8 = (unsigned char*)d_rgba8; ra.rgba_f32 = (float4*)d_rgba_f32;
   ra.num_local_pixels = npix; ra.spp = p->spp;
-  hipLaunchKernelGGL(resolve_kernel, dim3((unsigned)((npix + RBLOCK - 1) / RBLOCK)), dim3(RBLOCK), 0, stream, ra);
+  int P = 1, lg = 0;
+  while (P < p->spp) { P <<= 1; ++lg; }
+  if (p->spp > 1 && P <= 64) {
+    const long long ppb = TBLOCK >> lg;
+    hipLaunchKernelGGL(resolve_tree_kernel, dim3((unsigned)((npix + ppb - 1) / ppb)), dim3(TBLOCK), 0, stream, ra, P, lg);
+  } else {
+    hipLaunchKernelGGL(resolve_kernel, dim3((unsigned)((npix + RBLOCK - 1) / RBLOCK)), dim3(RBLOCK), 0, stream, ra);
+  }
   MIRT_HIP(hipGetLastError());
   if (sched && !wavefront) {
     // order for later frames.  It overwrites the buffer this context produced two uses ago; frames on other streams that
@@ -645,11 +704,7 @@ int render(MirtScene* sc, const MirtRenderParams* p, void* d_rgba8, void* d_rgba
       if (&c != &cx && c.used) MIRT_HIP(hipStreamWaitEvent(stream, c.ev2, 0));
     }
     uint32_t* out = cx.order_out[cx.uses & 1u];
-    MIRT_HIP(hipMemsetAsync(cx.sort_bins, 0, 4 * SORT_BINS, stream));
-    const unsigned gb = (unsigned)((nchunks + RBLOCK - 1) / RBLOCK);
-    hipLaunchKernelGGL(order_hist_kernel, dim3(gb), dim3(RBLOCK), 0, stream, cx.chunk_cost, (uint32_t)nchunks, cx.sort_bins);
-    hipLaunchKernelGGL(order_scan_kernel, dim3(1), dim3(SORT_BINS), 0, stream, cx.sort_bins);
-    hipLaunchKernelGGL(order_scatter_kernel, dim3(gb), dim3(RBLOCK), 0, stream, cx.chunk_cost, (uint32_t)nchunks, cx.sort_bins, out);
+    hipLaunchKernelGGL(order_kernel, dim3(1), dim3(SORT_BINS), 0, stream, cx.chunk_cost, (uint32_t)nchunks, out);
     MIRT_HIP(hipGetLastError());
     cx.order_key = nsamples;
   } else cx.order_key = -1;

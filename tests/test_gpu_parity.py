@@ -94,6 +94,7 @@ def test_tri_256_aa0_matches_oracle_and_golden_pixels(gpu_scenes, oracle_scenes)
     ("redchair", 96, 54, 0), ("redchair", 96, 54, 1), ("redchair", 64, 36, 32), ("redchair", 48, 27, 20),
     ("spiral", 160, 90, 1), ("spiral", 96, 54, 16),
     ("tenthousand", 160, 90, 1), ("tenthousand", 96, 54, 16), ("tenthousand", 40, 30, 40),
+    ("spiral", 24, 16, 100),      # next power of two > 64: the per-pixel fallback of the sample resolve
 ])
 def test_small_frames_match_oracle(name, w, h, spp, gpu_scenes, oracle_scenes):
     stl, raw = gpu_scenes(name)
