@@ -79,6 +79,9 @@ def main():
     ap.add_argument("--frames-in-flight", type=int, default=0,
                     help="consecutive frames overlapped on separate streams (1..4; default 2 on one GPU, 4 on several)")
     ap.add_argument("--serial", action="store_true", help="one frame in flight (no overlap of consecutive frames)")
+    ap.add_argument("--share-of", type=int, default=0,
+                    help="diagnostic: one process renders only part 0 of an N-way stripe partition (what one rank of N does, without "
+                         "the gather); the line then reports that share's rays and time, not a whole job")
     ap.add_argument("--png", default=None, help="write the last frame here (rank 0)")
     args = ap.parse_args()
 
@@ -116,16 +119,17 @@ def main():
     build_ms = m.build_lbvh_karas(raw)
 
     from cuda_ray_tracer_amd.tiles import StripePartition, FrameGatherer
-    stripe_rows = args.stripe_rows if world > 1 else H
-    partition = StripePartition(W, H, stripe_rows, world)
-    mine = partition.params(rank, SPP)
+    pworld, prank = (args.share_of, 0) if (args.share_of > 1 and world == 1) else (world, rank)
+    stripe_rows = args.stripe_rows if pworld > 1 else H
+    partition = StripePartition(W, H, stripe_rows, pworld)
+    mine = partition.params(prank, SPP)
     # Frames in flight: consecutive frames go to alternating streams, each with its own part buffer and (on rank 0) its own
     # gather buffers and frame, so the next frame's workgroups fill the CUs the draining frame frees (the drain of a frame
     # is one lane's 16-bounce chain, ~8 ms of latency).
-    nfl = args.frames_in_flight if args.frames_in_flight > 0 else (2 if world == 1 else 4)
+    nfl = args.frames_in_flight if args.frames_in_flight > 0 else (2 if pworld == 1 else 4)
     nfl = 1 if args.serial else max(1, min(4, nfl))
     streams = [torch.cuda.Stream(device=dev) for _ in range(nfl)]
-    gatherers = [FrameGatherer(partition, rank, world, dev) for _ in range(nfl)]
+    gatherers = [FrameGatherer(partition, prank, pworld, dev) for _ in range(nfl)]
     parts = [g.new_part_buffer(dev) for g in gatherers]
     part = parts[0]
     frame_no = [0]
@@ -140,7 +144,7 @@ def main():
         return parts[i]                                # N = 1: the part already is the whole row-major frame
 
     # untimed counting pass (same rays every frame: the RNG is keyed by pixel and sample index only)
-    cparams = partition.params(rank, SPP, counters=True)
+    cparams = partition.params(prank, SPP, counters=True)
     m.render(part, W, H, SPP, raw, params=cparams)
     torch.cuda.synchronize()
     cst = raw.stats()
@@ -194,7 +198,7 @@ def main():
             "dtype": "f32",
             "data": "bundled scene file scenes/%s.txt (the reference's own input); no synthetic substitution" % args.scene,
             "config": {"workload": f"{args.scene}.txt {W}x{H} {SPP}spp", "rays_per_frame": int(total_rays),
-                       "samples_per_frame": int(counts[5].item()), "parallelism": f"image stripes x{world}" if world > 1 else "single GPU", "frames_in_flight": nfl,
+                       "samples_per_frame": int(counts[5].item()), "parallelism": f"image stripes x{world}" if world > 1 else (f"DIAGNOSTIC: part 0 of {pworld} stripe sets on one GPU" if pworld > 1 else "single GPU"), "frames_in_flight": nfl,
                        "stripe_rows": stripe_rows, "lbvh_build_ms": build_ms},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": measured_traffic(f"{args.scene}.txt {W}x{H} {SPP}spp") if world == 1 else None, "kernel": "trace_kernel", "kernel_ms": mean_kernel_ms,

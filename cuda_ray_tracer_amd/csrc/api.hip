@@ -163,7 +163,7 @@ void mirt_scene_destroy(MirtScene* sc)
   for (int i = 0; i < mirt::MIRT_MAX_FRAMES; ++i) {
     mirt::RenderCtx& c = sc->ctx[i];
     hipFree(c.samples); hipFree(c.stack_spill); hipFree(c.pending); hipFree(c.counters); hipFree(c.prof); hipFree(c.args_dev);
-    hipFree(c.chunk_cost); hipFree(c.order_out[0]); hipFree(c.order_out[1]); hipFree(c.sort_bins);
+    hipFree(c.chunk_cost); for (uint32_t* o : c.order_out) hipFree(o);
     if (c.ev0) hipEventDestroy(c.ev0);
     if (c.ev1) hipEventDestroy(c.ev1);
     if (c.ev2) hipEventDestroy(c.ev2);

@@ -16,6 +16,7 @@
 #include "host_scene.h"
 #include "shade_common.h"
 
+#include <algorithm>
 #include <climits>
 #include <cmath>
 #include <cstdio>
@@ -26,7 +27,14 @@ namespace mirt {
 namespace {
 
 constexpr int RBLOCK = 256;
-constexpr int WORK_CHUNK = 256;       // samples a wave takes from the frame per atomic (shade_common.h assumes 256: g >> 8)
+// The trace kernel's waves never talk to each other, so a workgroup is one wave: a finished wave frees its slot (and its
+// 10 KB of LDS) at once instead of waiting for the slowest of four, which is what lets the next frame's waves move in
+// while this frame drains.
+#ifndef MIRT_TRACE_BLOCK
+#define MIRT_TRACE_BLOCK 64
+#endif
+constexpr int TRACE_BLOCK = MIRT_TRACE_BLOCK;
+constexpr int MAX_CHUNK_SHIFT = 8, MIN_CHUNK_SHIFT = 6;   // a wave takes 64..256 consecutive samples from the frame per atomic
 constexpr int DRAIN_LANES = 16;       // a wave with this few live lanes (and no work left to fetch) stops batching
 #ifndef MIRT_DEFAULT_WAVEFRONT
 #define MIRT_DEFAULT_WAVEFRONT 0
@@ -39,25 +47,27 @@ constexpr int DRAIN_LANES = 16;       // a wave with this few live lanes (and no
 #endif
 constexpr int STACK_LDS = MIRT_STACK_LDS;
 template <bool COUNT, bool PROF>
-__global__ void __launch_bounds__(RBLOCK, MIRT_WAVES_PER_SIMD) trace_kernel(const RenderArgs* __restrict__ ap, const HotArgs h)
+__global__ void __launch_bounds__(TRACE_BLOCK, MIRT_WAVES_PER_SIMD) trace_kernel(const RenderArgs* __restrict__ ap, const HotArgs h)
 {
   // PROF: diagnostic build only -- cycle stamps per phase, written to h.prof (never used for timing claims)
   unsigned long long pf_S = 0, pf_T = 0, pf_iters = 0, pf_active = 0, pf_Sent = 0, pf_Slanes = 0, pf_Bent = 0, pf_Blanes = 0, pf_leaf = 0, pf_node = 0;
   const unsigned long long pf_t0 = PROF ? clock64() : 0;
-  __shared__ __attribute__((aligned(16))) unsigned char lds_raw[STACK_LDS * RBLOCK * 4];     // traversal stacks: STACK_LDS x RBLOCK words
+  const unsigned long long pf_w0 = PROF ? wall_clock64() : 0;   // 100 MHz
+  unsigned long long pf_tx = 0;
+  __shared__ __attribute__((aligned(16))) unsigned char lds_raw[STACK_LDS * TRACE_BLOCK * 4];     // traversal stacks: STACK_LDS x TRACE_BLOCK words
   // The random-number state (8 words per lane) is only touched in the shade phase: it lives here during traversal so
   // that it does not occupy registers across the hot loop (the kernel runs at the 128-VGPR edge of 4 waves per SIMD).
-  __shared__ uint4 lds_rng[2][RBLOCK];
+  __shared__ uint4 lds_rng[2][TRACE_BLOCK];
   uint32_t* const lds_stack = reinterpret_cast<uint32_t*>(lds_raw);
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   (void)lane;
   const unsigned char* const heap = reinterpret_cast<const unsigned char*>(h.nodes);
-  const long long gid = (long long)blockIdx.x * RBLOCK + tid;
-  const long long gthreads = (long long)gridDim.x * RBLOCK;
+  const long long gid = (long long)blockIdx.x * TRACE_BLOCK + tid;
+  const long long gthreads = (long long)gridDim.x * TRACE_BLOCK;
   Counters cn = {0, 0, 0, 0, 0, 0, 0, 0};
 
-  // Work distribution: the sample range is cut into chunks of WORK_CHUNK consecutive samples (16 pixels at 16 spp); a wave
+  // Work distribution: the sample range is cut into chunks of 2^chunk_shift consecutive samples (16 pixels at 16 spp); a wave
   // takes the next chunk from a global counter whenever its local one is used up (one atomic per chunk), so waves that
   // draw cheap samples simply draw more of them -- this is what keeps the tail short when a GPU renders only a stripe set.
   unsigned long long c_next = 0, c_end = 0;   // wave-uniform: this wave's current chunk
@@ -101,7 +111,8 @@ __global__ void __launch_bounds__(RBLOCK, MIRT_WAVES_PER_SIMD) trace_kernel(cons
       if (need) {
         const int want = __popcll(need);
         const unsigned long long nsamples = (unsigned long long)a.num_samples;
-        const unsigned long long nchunks = (nsamples + WORK_CHUNK - 1) / WORK_CHUNK;
+        const unsigned long long chunk = 1ull << a.chunk_shift;
+        const unsigned long long nchunks = (nsamples + chunk - 1) >> a.chunk_shift;
         const int r = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(need >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)need, 0u));
         int given = 0;
         long long my = -1;
@@ -114,9 +125,9 @@ __global__ void __launch_bounds__(RBLOCK, MIRT_WAVES_PER_SIMD) trace_kernel(cons
               if (k < nchunks && a.chunk_order) k = a.chunk_order[k];
             }
             k = __shfl(k, 0);
-            if (k >= nchunks) { exhausted = true; break; }
-            c_next = k * WORK_CHUNK;
-            c_end = (c_next + WORK_CHUNK < nsamples) ? c_next + WORK_CHUNK : nsamples;
+            if (k >= nchunks) { exhausted = true; if (PROF && pf_tx == 0) pf_tx = wall_clock64(); break; }
+            c_next = k << a.chunk_shift;
+            c_end = (c_next + chunk < nsamples) ? c_next + chunk : nsamples;
           }
           const int avail = (int)(c_end - c_next);
           const int take = (want - given < avail) ? want - given : avail;
@@ -234,7 +245,7 @@ __global__ void __launch_bounds__(RBLOCK, MIRT_WAVES_PER_SIMD) trace_kernel(cons
             // on the stack, entry k < n sits in slot k and entry n is S.tos (slot 0 only ever receives the dead S.tos
             // of an empty stack), so the slot to write is simply the current depth.
             if (S.sp < STACK_TOTAL) {
-              if (S.sp < h.lds_depth) lds_stack[S.sp * RBLOCK + tid] = S.tos;
+              if (S.sp < h.lds_depth) lds_stack[S.sp * TRACE_BLOCK + tid] = S.tos;
               else h.stack_spill[(size_t)(S.sp - h.lds_depth) * gthreads + gid] = S.tos;
               S.tos = rref;
               ++S.sp;
@@ -250,7 +261,7 @@ __global__ void __launch_bounds__(RBLOCK, MIRT_WAVES_PER_SIMD) trace_kernel(cons
             S.cur = S.tos;
             --S.sp;
             // reload the new top (a dead read of slot 0 when the stack is now empty)
-            S.tos = lds_stack[(S.sp < h.lds_depth ? S.sp : 0) * RBLOCK + tid];
+            S.tos = lds_stack[(S.sp < h.lds_depth ? S.sp : 0) * TRACE_BLOCK + tid];
             if (S.sp >= h.lds_depth) S.tos = h.stack_spill[(size_t)(S.sp - h.lds_depth) * gthreads + gid];
           }
         }
@@ -264,6 +275,9 @@ __global__ void __launch_bounds__(RBLOCK, MIRT_WAVES_PER_SIMD) trace_kernel(cons
     atomicAdd(&h.prof[0], tot); atomicAdd(&h.prof[1], pf_S); atomicAdd(&h.prof[2], pf_T); atomicAdd(&h.prof[3], pf_iters);
     atomicAdd(&h.prof[4], pf_active); atomicAdd(&h.prof[5], pf_Sent); atomicAdd(&h.prof[6], pf_Slanes); atomicAdd(&h.prof[7], pf_Bent);
     atomicAdd(&h.prof[8], pf_Blanes); atomicAdd(&h.prof[9], pf_leaf); atomicAdd(&h.prof[10], 1ull);
+    // per wave: start, queue-empty and exit times (100 MHz wall clock)
+    unsigned long long* w = h.prof + 16 + 3 * (size_t)blockIdx.x * (TRACE_BLOCK / 64) + 3 * (tid >> 6);
+    w[0] = pf_w0; w[1] = pf_tx; w[2] = wall_clock64();
   }
   (void)pf_node;
 
@@ -517,7 +531,7 @@ static int grid_blocks(int device)
   hipDeviceProp_t prop;
   if (hipGetDeviceProperties(&prop, device) != hipSuccess) return 1024;
   int per_cu = 0;
-  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, trace_kernel<false, false>, RBLOCK, 0) != hipSuccess || per_cu < 1) per_cu = 4;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, trace_kernel<false, false>, TRACE_BLOCK, 0) != hipSuccess || per_cu < 1) per_cu = 4 * 256 / TRACE_BLOCK;
   return prop.multiProcessorCount * per_cu;
 }
 
@@ -537,9 +551,10 @@ int render(MirtScene* sc, const MirtRenderParams* p, void* d_rgba8, void* d_rgba
 
   static int blocks_cached = 0;
   if (!blocks_cached) blocks_cached = grid_blocks(sc->device);
-  long long want_blocks = (nsamples + RBLOCK - 1) / RBLOCK;
-  const int blocks = (int)(want_blocks < blocks_cached ? want_blocks : blocks_cached);
-  const size_t gthreads = (size_t)blocks * RBLOCK;
+  long long want_blocks = (nsamples + TRACE_BLOCK - 1) / TRACE_BLOCK;
+  int blocks = (int)(want_blocks < blocks_cached ? want_blocks : blocks_cached);
+  if (const char* e = getenv("MIRT_TRACE_WAVES")) { const int k = atoi(e); if (k >= 1 && k < blocks) blocks = k; }   // experiments
+  const size_t gthreads = (size_t)blocks * TRACE_BLOCK;
 
   // this frame's context; wait for the frame that used it MIRT_MAX_FRAMES renders ago
   RenderCtx& cx = sc->ctx[sc->frame_no % MIRT_MAX_FRAMES];
@@ -613,26 +628,33 @@ int render(MirtScene* sc, const MirtRenderParams* p, void* d_rgba8, void* d_rgba
   if (const char* e = getenv("MIRT_REFILL_K")) { int k = atoi(e); if (k >= 1 && k <= 64) a.refill_k = k; }
 
   // ---- longest-first chunk order (single-kernel path) ----------------------------------------------------------------
-  const size_t nchunks = (size_t)((nsamples + WORK_CHUNK - 1) / WORK_CHUNK);
+  // chunk size: 256 samples, smaller for a small (part of a) frame so that every wave still gets a dozen chunks or more --
+  // with four chunks per wave (1/8 of a 1080p frame) the waves finished up to a chunk apart
+  int chunk_shift = MAX_CHUNK_SHIFT;
+  while (chunk_shift > MIN_CHUNK_SHIFT && (nsamples >> chunk_shift) < 16ll * blocks * (TRACE_BLOCK / 64)) --chunk_shift;
+  if (const char* e = getenv("MIRT_CHUNK_SHIFT")) { const int k = atoi(e); if (k >= 4 && k <= 12) chunk_shift = k; }
+  a.chunk_shift = chunk_shift;
+  const size_t nchunks = (size_t)((nsamples + (1ll << chunk_shift) - 1) >> chunk_shift);
   if (cx.chunk_cap < nchunks) {
     MIRT_HIP(hipDeviceSynchronize());   // a frame on another stream may still be reading one of these orders
-    hipFree(cx.chunk_cost); hipFree(cx.order_out[0]); hipFree(cx.order_out[1]); hipFree(cx.sort_bins);
-    cx.chunk_cost = nullptr; cx.order_out[0] = cx.order_out[1] = nullptr; cx.sort_bins = nullptr; cx.chunk_cap = 0; cx.order_key = -1;
-    MIRT_HIP(hipMalloc(&cx.chunk_cost, 4 * nchunks)); MIRT_HIP(hipMalloc(&cx.order_out[0], 4 * nchunks));
-    MIRT_HIP(hipMalloc(&cx.order_out[1], 4 * nchunks)); MIRT_HIP(hipMalloc(&cx.sort_bins, 4 * SORT_BINS));
+    hipFree(cx.chunk_cost); cx.chunk_cost = nullptr; cx.chunk_cap = 0; cx.order_key = -1;
+    for (uint32_t*& o : cx.order_out) { hipFree(o); o = nullptr; }
+    MIRT_HIP(hipMalloc(&cx.chunk_cost, 4 * nchunks));
+    for (uint32_t*& o : cx.order_out) MIRT_HIP(hipMalloc(&o, 4 * nchunks));
     cx.chunk_cap = nchunks;
   }
-  // the newest finished frame with the same sample count provides the order; a frame that is still running does not
+  // the newest finished frame with the same sample count (and chunk size) provides the order; a frame that is still running does not
+  const long long okey = nsamples * 16 + chunk_shift;
   const uint32_t* order = nullptr;
   {
     unsigned long long best = 0;
     for (int i = 0; i < MIRT_MAX_FRAMES; ++i) {
       RenderCtx& c = sc->ctx[i];
-      if (&c == &cx || !c.used || c.order_key != nsamples || c.frame_id <= best) continue;
+      if (&c == &cx || !c.used || c.order_key != okey || c.frame_id <= best) continue;
       if (hipEventQuery(c.ev3) != hipSuccess) continue;
-      best = c.frame_id; order = c.order_out[(c.uses - 1) & 1u];
+      best = c.frame_id; order = c.order_out[(c.uses - 1) % RenderCtx::ORDER_BUFS];
     }
-    if (!order && cx.used && cx.order_key == nsamples) order = cx.order_out[(cx.uses - 1) & 1u];   // cx's own previous frame (finished: synchronised above)
+    if (!order && cx.used && cx.order_key == okey) order = cx.order_out[(cx.uses - 1) % RenderCtx::ORDER_BUFS];   // cx's own previous frame (finished: synchronised above)
   }
   static const bool sched = getenv("MIRT_NO_SCHED") == nullptr;
   if (!sched) order = nullptr;
@@ -665,21 +687,36 @@ int render(MirtScene* sc, const MirtRenderParams* p, void* d_rgba8, void* d_rgba
     h.prof = nullptr;
     if (!cx.args_dev) MIRT_HIP(hipMalloc(&cx.args_dev, sizeof(RenderArgs)));
     if (prof) {
-      if (!cx.prof) MIRT_HIP(hipMalloc(&cx.prof, 16 * sizeof(unsigned long long)));
-      MIRT_HIP(hipMemsetAsync(cx.prof, 0, 16 * sizeof(unsigned long long), stream));
+      const size_t nwaves = (size_t)blocks * (TRACE_BLOCK / 64);
+      if (cx.prof) { hipFree(cx.prof); cx.prof = nullptr; }
+      MIRT_HIP(hipMalloc(&cx.prof, (16 + 3 * nwaves) * sizeof(unsigned long long)));
+      MIRT_HIP(hipMemsetAsync(cx.prof, 0, (16 + 3 * nwaves) * sizeof(unsigned long long), stream));
       a.prof = cx.prof; h.prof = cx.prof;
     }
     MIRT_HIP(hipMemcpyAsync(cx.args_dev, &a, sizeof(RenderArgs), hipMemcpyHostToDevice, stream));
     if (prof) {
-      hipLaunchKernelGGL((trace_kernel<false, true>), dim3(blocks), dim3(RBLOCK), 0, stream, cx.args_dev, h);
+      hipLaunchKernelGGL((trace_kernel<false, true>), dim3(blocks), dim3(TRACE_BLOCK), 0, stream, cx.args_dev, h);
       MIRT_HIP(hipStreamSynchronize(stream));
       unsigned long long hh[16];
       MIRT_HIP(hipMemcpy(hh, cx.prof, sizeof(hh), hipMemcpyDeviceToHost));
       fprintf(stderr, "[mirt prof] waves=%llu cyc/wave=%.3g S=%.1f%% T=%.1f%% | T-iters/wave=%.0f active/iter=%.1f leaf-lanes/iter=%.1f | S-entries/wave=%.0f lanes/entry=%.1f | B-entries/wave=%.0f lanes/entry=%.1f\n",
               hh[10], (double)hh[0] / hh[10], 100.0 * hh[1] / hh[0], 100.0 * hh[2] / hh[0], (double)hh[3] / hh[10], (double)hh[4] / (hh[3] ? hh[3] : 1), (double)hh[9] / (hh[3] ? hh[3] : 1),
               (double)hh[5] / hh[10], (double)hh[6] / (hh[5] ? hh[5] : 1), (double)hh[7] / hh[10], (double)hh[8] / (hh[7] ? hh[7] : 1));
-    } else if (count) hipLaunchKernelGGL((trace_kernel<true, false>), dim3(blocks), dim3(RBLOCK), 0, stream, cx.args_dev, h);
-    else hipLaunchKernelGGL((trace_kernel<false, false>), dim3(blocks), dim3(RBLOCK), 0, stream, cx.args_dev, h);
+      {
+        const size_t nwaves = (size_t)blocks * (TRACE_BLOCK / 64);
+        std::vector<unsigned long long> w(3 * nwaves);
+        MIRT_HIP(hipMemcpy(w.data(), cx.prof + 16, w.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+        unsigned long long t0 = ~0ull;
+        for (size_t i = 0; i < nwaves; ++i) if (w[3 * i] && w[3 * i] < t0) t0 = w[3 * i];
+        std::vector<double> st, ex, en;
+        for (size_t i = 0; i < nwaves; ++i) { st.push_back((w[3 * i] - t0) * 1e-5); ex.push_back(((w[3 * i + 1] ? w[3 * i + 1] : w[3 * i + 2]) - t0) * 1e-5); en.push_back((w[3 * i + 2] - t0) * 1e-5); }
+        std::sort(st.begin(), st.end()); std::sort(ex.begin(), ex.end()); std::sort(en.begin(), en.end());
+        auto q = [&](const std::vector<double>& v, double f) { return v[(size_t)(f * (v.size() - 1))]; };
+        fprintf(stderr, "[mirt prof] per-wave times, ms (min/10%%/50%%/90%%/max): start %.2f/%.2f/%.2f/%.2f/%.2f | queue empty %.2f/%.2f/%.2f/%.2f/%.2f | exit %.2f/%.2f/%.2f/%.2f/%.2f\n",
+                q(st, 0), q(st, .1), q(st, .5), q(st, .9), q(st, 1), q(ex, 0), q(ex, .1), q(ex, .5), q(ex, .9), q(ex, 1), q(en, 0), q(en, .1), q(en, .5), q(en, .9), q(en, 1));
+      }
+    } else if (count) hipLaunchKernelGGL((trace_kernel<true, false>), dim3(blocks), dim3(TRACE_BLOCK), 0, stream, cx.args_dev, h);
+    else hipLaunchKernelGGL((trace_kernel<false, false>), dim3(blocks), dim3(TRACE_BLOCK), 0, stream, cx.args_dev, h);
   }
   MIRT_HIP(hipGetLastError());
   MIRT_HIP(hipEventRecord(cx.ev2, stream));
@@ -697,16 +734,12 @@ int render(MirtScene* sc, const MirtRenderParams* p, void* d_rgba8, void* d_rgba
   }
   MIRT_HIP(hipGetLastError());
   if (sched && !wavefront) {
-    // order for later frames.  It overwrites the buffer this context produced two uses ago; frames on other streams that
-    // might still read that buffer are older than this one, so the sort waits for their trace kernels.
-    for (int i = 0; i < MIRT_MAX_FRAMES; ++i) {
-      RenderCtx& c = sc->ctx[i];
-      if (&c != &cx && c.used) MIRT_HIP(hipStreamWaitEvent(stream, c.ev2, 0));
-    }
-    uint32_t* out = cx.order_out[cx.uses & 1u];
+    // order for later frames.  It overwrites the buffer this context wrote three uses (12 frames) ago; every frame that
+    // could have read that one has finished -- the host waited for each of them when it reused their contexts.
+    uint32_t* out = cx.order_out[cx.uses % RenderCtx::ORDER_BUFS];
     hipLaunchKernelGGL(order_kernel, dim3(1), dim3(SORT_BINS), 0, stream, cx.chunk_cost, (uint32_t)nchunks, out);
     MIRT_HIP(hipGetLastError());
-    cx.order_key = nsamples;
+    cx.order_key = okey;
   } else cx.order_key = -1;
   ++cx.uses;
   MIRT_HIP(hipEventRecord(cx.ev3, stream));

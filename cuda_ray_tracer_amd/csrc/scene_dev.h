@@ -65,6 +65,7 @@ struct RenderArgs {
   unsigned long long* prof;       // diagnostic build only (MIRT_PROF)
   unsigned long long* work_counter; // next unclaimed chunk of the frame (single-kernel path)
   const uint32_t* chunk_order;      // chunk k of the hand-out order is chunk chunk_order[k] of the frame (null: identity)
+  int chunk_shift;                  // log2 of the number of consecutive samples a wave takes from the frame per atomic
   uint32_t* chunk_cost;             // per chunk: the largest number of traversal steps one of its samples took
 };
 
@@ -112,12 +113,15 @@ struct RenderCtx {
   // longest-first scheduling: this frame's per-chunk cost, and the hand-out orders computed from it (two buffers used in
   // turn, so that a frame still reading an order never sees it rewritten)
   uint32_t* chunk_cost = nullptr;
-  uint32_t* order_out[2] = {nullptr, nullptr};
-  uint32_t* sort_bins = nullptr;
+  // chunk orders this context produced, used round-robin.  Three of them: the one written at use u is next written at use
+  // u + 3, i.e. 12 frames later, and by then the host has waited (on context reuse) for every frame that could read it --
+  // so no frame ever needs a device-side wait on another frame's stream.
+  static constexpr unsigned ORDER_BUFS = 3;
+  uint32_t* order_out[ORDER_BUFS] = {nullptr, nullptr, nullptr};
   size_t chunk_cap = 0;
   unsigned uses = 0;
   unsigned long long frame_id = 0;         // sequence number of the frame that last used this context
-  long long order_key = -1;                // num_samples the order in order_out[(uses - 1) & 1] was computed for
+  long long order_key = -1;                // num_samples the order in order_out[(uses - 1) % ORDER_BUFS] was computed for
   float wf_trace_ms = -1.0f;               // >= 0: the wavefront path ran; summed trace-kernel time
 };
 

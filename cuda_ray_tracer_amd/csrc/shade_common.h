@@ -434,7 +434,7 @@ MIRT_DEV void advance(const RenderArgs& a, Lane& S, Counters& cn, const long lon
   const int micro = advance_core<COUNT>(a, S, cn, gid, gthreads);
   if (micro == M_DONE) {
     a.samples[S.g] = make_float4(S.L.x, S.L.y, S.L.z, S.alpha);
-    if (a.chunk_cost) atomicMax(&a.chunk_cost[S.g >> 8], S.steps);     // WORK_CHUNK = 256 samples
+    if (a.chunk_cost) atomicMax(&a.chunk_cost[S.g >> a.chunk_shift], S.steps);
     S.g = -1;
     S.trav = false;
   } else if (micro == M_BATCH) {
