@@ -22,7 +22,7 @@ txt = open(out).read().splitlines()
 inside = False
 body = []
 for l in txt:
-    if re.match(r"^_ZN4mirt.*trace_kernelILb0ELb0ELi0.*:", l):
+    if re.match(r"^_ZN4mirt.*trace_kernelILb0ELb0.*:", l):
         inside = True; continue
     if inside and "s_endpgm" in l:
         break
