@@ -56,6 +56,7 @@ __global__ void __launch_bounds__(TRACE_BLOCK, MIRT_WAVES_PER_SIMD) trace_kernel
   unsigned long long pf_S = 0, pf_T = 0, pf_iters = 0, pf_active = 0, pf_Sent = 0, pf_Slanes = 0, pf_Bent = 0, pf_Blanes = 0, pf_leaf = 0, pf_node = 0;
   const unsigned long long pf_t0 = PROF ? clock64() : 0;
   const unsigned long long pf_w0 = PROF ? wall_clock64() : 0;   // 100 MHz
+  unsigned long long pf_adv = 0, pf_adv_it = 0;
   unsigned long long pf_tx = 0, pf_xit = 0, pf_xS = 0, pf_help = 0, pf_dit = 0, pf_xact = 0;
   __shared__ __attribute__((aligned(16))) unsigned char lds_raw[STACK_LDS * TRACE_BLOCK * 4];     // traversal stacks: STACK_LDS x TRACE_BLOCK words
   // The random-number state (8 words per lane) is only touched in the shade phase: it lives here during traversal so
@@ -111,7 +112,9 @@ __global__ void __launch_bounds__(TRACE_BLOCK, MIRT_WAVES_PER_SIMD) trace_kernel
     while (!S.trav && S.g >= 0 && !(exhausted && S.batch_pending)) {
       if (S.batch_pending) batch_next<COUNT>(a, S, cn);
       else advance<COUNT>(a, S, cn, gid, gthreads);
+      if (PROF) pf_adv_it++;
     }
+    if (PROF) pf_adv += clock64() - pf_a;
     if (!exhausted) {
       const unsigned long long need = __ballot(!S.trav && S.g < 0);
       if (need) {
@@ -284,31 +287,29 @@ __global__ void __launch_bounds__(TRACE_BLOCK, MIRT_WAVES_PER_SIMD) trace_kernel
           bool hl, hr;
           box_pair(q0, q1, q2, S.o.x, S.o.y, S.o.z, S.inv.x, S.inv.y, S.inv.z, S.tbest, tmin, hl, hr);
           const uint32_t lref = ch.x, rref = ch.y;
-          if (hl && hr) {
-            S.cur = lref;
-            // push right: the previous top of stack goes to memory, the new top stays in a register.  With n entries
-            // on the stack, entry k < n sits in slot k and entry n is S.tos (slot 0 only ever receives the dead S.tos
-            // of an empty stack), so the slot to write is simply the current depth.
-            if (S.sp < STACK_TOTAL) {
-              if (S.sp < h.lds_depth) lds_stack[S.sp * TRACE_BLOCK + tid] = S.tos;
-              else h.stack_spill[(size_t)(S.sp - h.lds_depth) * gthreads + gid] = S.tos;
-              S.tos = rref;
-              ++S.sp;
-              if (COUNT) cn.max_stack = max(cn.max_stack, (uint32_t)S.sp);
-            }
-          } else if (hl) S.cur = lref;
-          else if (hr) S.cur = rref;
-          else pop = true;
+          // left first, push right (bvh_traversal.cu:149-157), written with selects: one short branch for the push
+          const bool both = hl && hr;
+          if (both && S.sp < STACK_TOTAL) {
+            // the previous top of stack goes to memory, the new top stays in a register.  With n entries on the stack,
+            // entry k < n sits in slot k and entry n is S.tos (slot 0 only ever receives the dead S.tos of an empty
+            // stack), so the slot to write is simply the current depth.
+            if (S.sp < h.lds_depth) lds_stack[S.sp * TRACE_BLOCK + tid] = S.tos;
+            else h.stack_spill[(size_t)(S.sp - h.lds_depth) * gthreads + gid] = S.tos;
+            S.tos = rref;
+            ++S.sp;
+            if (COUNT) cn.max_stack = max(cn.max_stack, (uint32_t)S.sp);
+          }
+          S.cur = hl ? lref : (hr ? rref : S.cur);
+          pop = !(hl || hr);
         }
         if (pop) {
-          if (S.sp == 0) S.trav = false;
-          else {
-            S.cur = S.tos;
-            --S.sp;
-            // reload the new top (a dead read of slot 0 when the stack is now empty)
-            S.tos = lds_stack[(S.sp < h.lds_depth ? S.sp : 0) * TRACE_BLOCK + tid];
-            if (S.sp >= h.lds_depth) S.tos = h.stack_spill[(size_t)(S.sp - h.lds_depth) * gthreads + gid];
-          }
+          // an empty stack ends the traversal; otherwise the top becomes the current node and the new top is reloaded
+          // (a dead read of slot 0 when the stack is now empty)
+          S.trav = S.sp != 0;
+          S.cur = S.tos;
+          S.sp = S.sp > 0 ? S.sp - 1 : 0;
+          S.tos = lds_stack[(S.sp < h.lds_depth ? S.sp : 0) * TRACE_BLOCK + tid];
+          if (S.sp >= h.lds_depth) S.tos = h.stack_spill[(size_t)(S.sp - h.lds_depth) * gthreads + gid];
         }
       }
     }
@@ -320,6 +321,7 @@ __global__ void __launch_bounds__(TRACE_BLOCK, MIRT_WAVES_PER_SIMD) trace_kernel
     atomicAdd(&h.prof[0], tot); atomicAdd(&h.prof[1], pf_S); atomicAdd(&h.prof[2], pf_T); atomicAdd(&h.prof[3], pf_iters);
     atomicAdd(&h.prof[4], pf_active); atomicAdd(&h.prof[5], pf_Sent); atomicAdd(&h.prof[6], pf_Slanes); atomicAdd(&h.prof[7], pf_Bent);
     atomicAdd(&h.prof[8], pf_Blanes); atomicAdd(&h.prof[9], pf_leaf); atomicAdd(&h.prof[10], 1ull);
+    atomicAdd(&h.prof[16 + 3 * (size_t)gridDim.x * (TRACE_BLOCK / 64)], pf_adv); atomicAdd(&h.prof[17 + 3 * (size_t)gridDim.x * (TRACE_BLOCK / 64)], pf_adv_it);
     atomicAdd(&h.prof[11], pf_xit); atomicAdd(&h.prof[12], pf_xS); atomicAdd(&h.prof[13], pf_help); atomicAdd(&h.prof[14], pf_dit); atomicAdd(&h.prof[15], pf_xact);
     // per wave: start, queue-empty and exit times (100 MHz wall clock)
     unsigned long long* w = h.prof + 16 + 3 * (size_t)blockIdx.x * (TRACE_BLOCK / 64) + 3 * (tid >> 6);
@@ -735,8 +737,8 @@ int render(MirtScene* sc, const MirtRenderParams* p, void* d_rgba8, void* d_rgba
     if (prof) {
       const size_t nwaves = (size_t)blocks * (TRACE_BLOCK / 64);
       if (cx.prof) { hipFree(cx.prof); cx.prof = nullptr; }
-      MIRT_HIP(hipMalloc(&cx.prof, (16 + 3 * nwaves) * sizeof(unsigned long long)));
-      MIRT_HIP(hipMemsetAsync(cx.prof, 0, (16 + 3 * nwaves) * sizeof(unsigned long long), stream));
+      MIRT_HIP(hipMalloc(&cx.prof, (18 + 3 * nwaves) * sizeof(unsigned long long)));
+      MIRT_HIP(hipMemsetAsync(cx.prof, 0, (18 + 3 * nwaves) * sizeof(unsigned long long), stream));
       a.prof = cx.prof; h.prof = cx.prof;
     }
     MIRT_HIP(hipMemcpyAsync(cx.args_dev, &a, sizeof(RenderArgs), hipMemcpyHostToDevice, stream));
@@ -748,6 +750,12 @@ int render(MirtScene* sc, const MirtRenderParams* p, void* d_rgba8, void* d_rgba
       fprintf(stderr, "[mirt prof] waves=%llu cyc/wave=%.3g S=%.1f%% T=%.1f%% | T-iters/wave=%.0f active/iter=%.1f leaf-lanes/iter=%.1f | S-entries/wave=%.0f lanes/entry=%.1f | B-entries/wave=%.0f lanes/entry=%.1f\n",
               hh[10], (double)hh[0] / hh[10], 100.0 * hh[1] / hh[0], 100.0 * hh[2] / hh[0], (double)hh[3] / hh[10], (double)hh[4] / (hh[3] ? hh[3] : 1), (double)hh[9] / (hh[3] ? hh[3] : 1),
               (double)hh[5] / hh[10], (double)hh[6] / (hh[5] ? hh[5] : 1), (double)hh[7] / hh[10], (double)hh[8] / (hh[7] ? hh[7] : 1));
+      {
+        unsigned long long ad[2];
+        MIRT_HIP(hipMemcpy(ad, cx.prof + 16 + 3 * (size_t)blocks * (TRACE_BLOCK / 64), sizeof(ad), hipMemcpyDeviceToHost));
+        fprintf(stderr, "[mirt prof] shade phase: %.1f%% of it in the advance/batch loop (%.2f passes per entry), the rest in refill + init_sample + RNG load/store\n",
+                100.0 * ad[0] / (hh[1] ? hh[1] : 1), (double)ad[1] / (hh[5] ? hh[5] : 1));
+      }
       fprintf(stderr, "[mirt prof] after the queue is empty, per wave: %.0f iterations (%.1f lanes traversing, %.0f in drain mode), %.1f shade-phase entries, %.1f shadow rays lent to idle lanes\n",
               (double)hh[11] / hh[10], (double)hh[15] / (hh[11] ? hh[11] : 1), (double)hh[14] / hh[10], (double)hh[12] / hh[10], (double)hh[13] / hh[10]);
       {
