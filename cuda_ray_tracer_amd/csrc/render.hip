@@ -235,44 +235,39 @@ __global__ void __launch_bounds__(TRACE_BLOCK, MIRT_WAVES_PER_SIMD) trace_kernel
           bool hit = false;
           const float4 q0 = rec[0];
           if (S.cur & REF_TRI) {
-            // checkTriangleIntersectionSoA, struct.cu:111-163
+            // checkTriangleIntersectionSoA, struct.cu:111-163.  The early returns of the reference become one boolean:
+            // a wave with several lanes here never skips the code anyway, and values computed past a failed test
+            // (a division by ~0, a barycentric of a point behind the ray) are simply not selected.
             if (COUNT) cn.tri_tests++;
             const float4 q1 = rec[1], q2 = rec[2];
             const f3 p0 = mk3(q0.x, q0.y, q0.z), nor = mk3(q0.w, q1.x, q1.y);
             const float denom = dot(S.d, nor);
-            if (!(fabsf(denom) < 1e-9f)) {
-              t = dot(p0 - S.o, nor) / denom;
-              if (!(t <= EPSILON)) {
-                const f3 ip = t * S.d + S.o;
-                const f3 e1 = mk3(q1.z, q1.w, q2.x), e2 = mk3(q2.y, q2.z, q2.w);
-                const float b1 = dot(e1, ip - p0);
-                const float b2 = dot(e2, ip - p0);
-                const float b0 = 1.0f - b1 - b2;
-                hit = (b0 >= -EPSILON) && (b1 >= -EPSILON) && (b2 >= -EPSILON);
-              }
-            }
+            t = dot(p0 - S.o, nor) / denom;
+            const f3 ip = t * S.d + S.o;
+            const f3 e1 = mk3(q1.z, q1.w, q2.x), e2 = mk3(q2.y, q2.z, q2.w);
+            const float b1 = dot(e1, ip - p0);
+            const float b2 = dot(e2, ip - p0);
+            const float b0 = 1.0f - b1 - b2;
+            hit = !(fabsf(denom) < 1e-9f) && !(t <= EPSILON) && (b0 >= -EPSILON) && (b1 >= -EPSILON) && (b2 >= -EPSILON);
           } else {
-            // checkSphereIntersectionSoA, struct.cu:64-109
+            // checkSphereIntersectionSoA, struct.cu:64-109 (same remark)
             if (COUNT) cn.sphere_tests++;
             const f3 c = mk3(q0.x, q0.y, q0.z);
             const float r = q0.w;
             const f3 cr0 = c - S.o;
             const bool inside = (dot(cr0, cr0) < r * r);
             const float tc = dot(cr0, S.d);
-            if (!(!inside && tc < 0.0f)) {
-              const f3 dv = S.o + (tc * S.d) - c;
-              const float d2 = dot(dv, dv);
-              if (!(!inside && (r * r) < d2)) {
-                const float toff = sqrtf((r * r) - d2);
-                t = inside ? (tc + toff) : (tc - toff);
-                hit = true;
-              }
-            }
+            const f3 dv = S.o + (tc * S.d) - c;
+            const float d2 = dot(dv, dv);
+            const float toff = sqrtf((r * r) - d2);
+            t = inside ? (tc + toff) : (tc - toff);
+            hit = !(!inside && tc < 0.0f) && !(!inside && (r * r) < d2);
           }
-          if (hit && t > 1e-6f && t < S.tbest) {
-            S.tbest = t; S.refbest = S.cur;
-            if (S.shadow && S.tbest < S.limit) S.trav = false;      // any-hit exit
-          }
+          // (S.trav is true here)
+          const bool closer = hit && t > 1e-6f && t < S.tbest;
+          S.tbest = closer ? t : S.tbest;
+          S.refbest = closer ? S.cur : S.refbest;
+          S.trav = !(closer && S.shadow && t < S.limit);      // any-hit exit
           pop = S.trav;
         } else {
           if (COUNT) cn.internal_visits++;
