@@ -34,9 +34,6 @@ constexpr int RBLOCK = 256;
 #define MIRT_TRACE_BLOCK 64
 #endif
 constexpr int TRACE_BLOCK = MIRT_TRACE_BLOCK;
-#ifndef MIRT_HELPERS
-#define MIRT_HELPERS 0   // measured: the drain gets 18 % fewer iterations, but the extra live state costs the whole loop 7 %
-#endif
 constexpr int MAX_CHUNK_SHIFT = 8, MIN_CHUNK_SHIFT = 6;   // a wave takes 64..256 consecutive samples from the frame per atomic
 constexpr int DRAIN_LANES = 16;       // a wave with this few live lanes (and no work left to fetch) stops batching
 #ifndef MIRT_DEFAULT_WAVEFRONT
@@ -57,7 +54,7 @@ __global__ void __launch_bounds__(TRACE_BLOCK, MIRT_WAVES_PER_SIMD) trace_kernel
   const unsigned long long pf_t0 = PROF ? clock64() : 0;
   const unsigned long long pf_w0 = PROF ? wall_clock64() : 0;   // 100 MHz
   unsigned long long pf_adv = 0, pf_adv_it = 0;
-  unsigned long long pf_tx = 0, pf_xit = 0, pf_xS = 0, pf_help = 0, pf_dit = 0, pf_xact = 0;
+  unsigned long long pf_tx = 0, pf_xit = 0, pf_xS = 0, pf_dit = 0, pf_xact = 0;
   __shared__ __attribute__((aligned(16))) unsigned char lds_raw[STACK_LDS * TRACE_BLOCK * 4];     // traversal stacks: STACK_LDS x TRACE_BLOCK words
   // The random-number state (8 words per lane) is only touched in the shade phase: it lives here during traversal so
   // that it does not occupy registers across the hot loop (the kernel runs at the 128-VGPR edge of 4 waves per SIMD).
@@ -85,7 +82,7 @@ __global__ void __launch_bounds__(TRACE_BLOCK, MIRT_WAVES_PER_SIMD) trace_kernel
   S.Hbounce = 0; S.Hior = 1.458f; S.Hrough = 0.0f; S.HtransNZ = false;
   S.wt = mk3(1, 1, 1); S.wD = mk3(0, 0, 0); S.pn = mk3(0, 0, 0);
   S.pc = 0; S.refr_bounce = 0; S.gi_n = 0; S.state = ST_PRIMARY;
-  S.bo = mk3(0, 0, 0); S.rdir = mk3(0, 0, 1); S.li = 0; S.hx = 0; S.occl = 0ull; S.batch_pending = false; S.has_reflect = false;
+  S.bo = mk3(0, 0, 0); S.rdir = mk3(0, 0, 1); S.li = 0; S.occl = 0ull; S.batch_pending = false; S.has_reflect = false;
   S.o = mk3(0, 0, 0); S.d = mk3(0, 0, 1); S.inv = mk3(0, 0, 1); S.bounce = 0; S.limit = INFINITY; S.shadow = false;
   S.tplane = INFINITY; S.plane_id = -1;
   S.cur = REF_NONE; S.tos = REF_NONE; S.sp = 0; S.tbest = INFINITY; S.refbest = REF_NONE;
@@ -107,8 +104,7 @@ __global__ void __launch_bounds__(TRACE_BLOCK, MIRT_WAVES_PER_SIMD) trace_kernel
       S.rng.v0 = r0.x; S.rng.v1 = r0.y; S.rng.v2 = r0.z; S.rng.v3 = r0.w;
       S.rng.v4 = r1.x; S.rng.d = r1.y; S.rng.bm_extra = __uint_as_float(r1.z); S.rng.bm_flag = (int)r1.w;
     }
-    // (once the frame's queue is empty, the rays of a batch are started in the traversal loop's header, where a draining
-    // wave first offers the shadow rays to its idle lanes)
+    // (once the frame's queue is empty the first ray of a new batch is started by the traversal loop's header instead)
     while (!S.trav && S.g >= 0 && !(exhausted && S.batch_pending)) {
       if (S.batch_pending) batch_next<COUNT>(a, S, cn);
       else advance<COUNT>(a, S, cn, gid, gthreads);
@@ -170,44 +166,6 @@ __global__ void __launch_bounds__(TRACE_BLOCK, MIRT_WAVES_PER_SIMD) trace_kernel
       const int nlive = __popcll(__ballot(S.g >= 0));
       const bool drain = exhausted && nlive <= h.drain_lanes;
       if (nwait >= h.refill_k || (drain && nwait > 0)) break;
-      // Draining wave (nothing left to fetch, few live lanes): a sample's bounce is three rays one after the other -- two
-      // shadow rays and the reflection ray -- and the idle lanes could trace the shadow rays meanwhile.  An idle lane
-      // borrows (origin, light) from an owner lane, runs that one shadow ray through the same batch_next / traversal
-      // code, and the owner collects the occlusion bit before it shades.  Same rays, same results and counters; the
-      // drain's critical path gets shorter, which is what a small part of a frame (one GPU of eight) spends its time on.
-#if MIRT_HELPERS
-      if (drain) {
-        const int nl = h.num_suns + h.num_bulbs;
-        unsigned long long dm = __ballot(S.g == G_HELPER_DONE);
-        const int my_bit = (S.g == G_HELPER_DONE) ? (int)((S.occl >> S.li) & 1ull) : 0;
-        while (dm) {
-          const int f = __ffsll((long long)dm) - 1;
-          dm &= dm - 1;
-          const int owner = __builtin_amdgcn_readlane(S.hx, f) >> 8;
-          const int l = __builtin_amdgcn_readlane(S.li, f);
-          const int bit = __builtin_amdgcn_readlane(my_bit, f);
-          if (lane == owner) { S.occl |= (unsigned long long)bit << l; S.hx -= 0x100; }
-          if (lane == f) S.g = G_FREE;
-        }
-        unsigned long long freem = __ballot(S.g == G_FREE && !S.trav);
-        unsigned long long ownm = __ballot(S.g >= 0 && S.batch_pending && (S.hx & 0xff) < nl);
-        while (freem && ownm) {
-          const int o = __ffsll((long long)ownm) - 1, f = __ffsll((long long)freem) - 1;
-          const int l = __builtin_amdgcn_readlane(S.hx, o) & 0xff;
-          const float bx = __shfl(S.bo.x, o), by = __shfl(S.bo.y, o), bz = __shfl(S.bo.z, o);
-          const float px = __shfl(S.Hp.x, o), py = __shfl(S.Hp.y, o), pz = __shfl(S.Hp.z, o);
-          if (lane == f) {
-            S.g = G_HELPER; S.hx = l | (o << 8); S.li = -1; S.occl = 0ull;
-            S.bo = mk3(bx, by, bz); S.Hp = mk3(px, py, pz);
-            S.batch_pending = true; S.has_reflect = false; S.shadow = false;
-          }
-          if (lane == o) S.hx += 0x101;          // that light is taken, one more helper is out
-          if (PROF) pf_help++;
-          freem &= freem - 1;
-          if (l + 1 >= nl) ownm &= ownm - 1;
-        }
-      }
-#endif
       // lanes whose batch ray finished move on to the next ray of their batch (cheap; done in groups)
       if (bm != 0 && (__popcll(bm) >= h.batch_k || tm == 0 || drain)) {
         if (PROF) { pf_Bent++; pf_Blanes += __popcll(bm); }
@@ -317,7 +275,7 @@ __global__ void __launch_bounds__(TRACE_BLOCK, MIRT_WAVES_PER_SIMD) trace_kernel
     atomicAdd(&h.prof[4], pf_active); atomicAdd(&h.prof[5], pf_Sent); atomicAdd(&h.prof[6], pf_Slanes); atomicAdd(&h.prof[7], pf_Bent);
     atomicAdd(&h.prof[8], pf_Blanes); atomicAdd(&h.prof[9], pf_leaf); atomicAdd(&h.prof[10], 1ull);
     atomicAdd(&h.prof[16 + 3 * (size_t)gridDim.x * (TRACE_BLOCK / 64)], pf_adv); atomicAdd(&h.prof[17 + 3 * (size_t)gridDim.x * (TRACE_BLOCK / 64)], pf_adv_it);
-    atomicAdd(&h.prof[11], pf_xit); atomicAdd(&h.prof[12], pf_xS); atomicAdd(&h.prof[13], pf_help); atomicAdd(&h.prof[14], pf_dit); atomicAdd(&h.prof[15], pf_xact);
+    atomicAdd(&h.prof[11], pf_xit); atomicAdd(&h.prof[12], pf_xS); atomicAdd(&h.prof[14], pf_dit); atomicAdd(&h.prof[15], pf_xact);
     // per wave: start, queue-empty and exit times (100 MHz wall clock)
     unsigned long long* w = h.prof + 16 + 3 * (size_t)blockIdx.x * (TRACE_BLOCK / 64) + 3 * (tid >> 6);
     w[0] = pf_w0; w[1] = pf_tx; w[2] = wall_clock64();
@@ -751,8 +709,8 @@ int render(MirtScene* sc, const MirtRenderParams* p, void* d_rgba8, void* d_rgba
         fprintf(stderr, "[mirt prof] shade phase: %.1f%% of it in the advance/batch loop (%.2f passes per entry), the rest in refill + init_sample + RNG load/store\n",
                 100.0 * ad[0] / (hh[1] ? hh[1] : 1), (double)ad[1] / (hh[5] ? hh[5] : 1));
       }
-      fprintf(stderr, "[mirt prof] after the queue is empty, per wave: %.0f iterations (%.1f lanes traversing, %.0f in drain mode), %.1f shade-phase entries, %.1f shadow rays lent to idle lanes\n",
-              (double)hh[11] / hh[10], (double)hh[15] / (hh[11] ? hh[11] : 1), (double)hh[14] / hh[10], (double)hh[12] / hh[10], (double)hh[13] / hh[10]);
+      fprintf(stderr, "[mirt prof] after the queue is empty, per wave: %.0f iterations (%.1f lanes traversing, %.0f in drain mode), %.1f shade-phase entries\n",
+              (double)hh[11] / hh[10], (double)hh[15] / (hh[11] ? hh[11] : 1), (double)hh[14] / hh[10], (double)hh[12] / hh[10]);
       {
         const size_t nwaves = (size_t)blocks * (TRACE_BLOCK / 64);
         std::vector<unsigned long long> w(3 * nwaves);

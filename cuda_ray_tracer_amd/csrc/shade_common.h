@@ -124,10 +124,6 @@ MIRT_DEV void box_pair(const float4 q0, const float4 q1, const float4 q2, float 
   hr = te < tx && te < tbest && tx > tmin;
 }
 
-// Lane.g of a lane that holds no sample: free, or (single-kernel path, draining waves only) lent to another lane of the
-// wave to trace one shadow ray of that lane's ray batch
-constexpr long long G_FREE = -1, G_HELPER = -2, G_HELPER_DONE = -3;
-
 struct Counters { uint32_t samples, rays, shadow_rays, internal_visits, sphere_tests, tri_tests, mat_fetches, max_stack; };
 
 // Everything a lane carries from one loop iteration to the next.
@@ -147,9 +143,7 @@ struct Lane {
   int pc, refr_bounce, gi_n, state;
   // the node's ray batch: shadow rays to every light, then the reflection ray; all leave from bo
   f3 bo, rdir;
-  int li;                      // index of the batch ray in flight: < nlights shadow, == nlights reflection, > nlights: all started
-  int hx;                      // bits 0..7: next light whose shadow ray has not been started; bits 8..: owner lane: shadow
-                               // rays of this batch that helper lanes are tracing; helper lane: the owner's lane number
+  int li;                      // index of the batch ray in flight: < nlights shadow, == nlights reflection
   unsigned long long occl;     // bit i: light i is occluded
   bool batch_pending, has_reflect;
   // ray in flight
@@ -205,16 +199,12 @@ MIRT_DEV void batch_next(const Args& a, Lane& S, Counters& cn)
     const bool occluded = (S.plane_id >= 0 && S.tplane < S.limit) || (S.refbest != REF_NONE && S.tbest < S.limit);
     if (occluded) S.occl |= 1ull << S.li;
   }
-  // a helper lane traces one shadow ray for another lane; the owner collects the bit (trace_kernel, drain mode)
-  if (S.g == G_HELPER && S.li >= 0) { S.g = G_HELPER_DONE; S.batch_pending = false; S.shadow = false; S.trav = false; return; }
+  ++S.li;
   // the lanes of a wave are at different rays of their batches: each kind only sets the ray up, and all of them share
   // one start_ray (one copy of the plane loop instead of three executed one after the other)
   bool go = true;
-  const int lnext = S.hx & 0xff;
-  if (lnext < nlights) {
+  if (S.li < nlights) {
     // shadow ray, draw.cu:346 / 362-363
-    S.li = lnext;
-    S.hx += 1;
     S.o = S.bo;
     S.limit = INFINITY;
     S.shadow = true;
@@ -230,18 +220,14 @@ MIRT_DEV void batch_next(const Args& a, Lane& S, Counters& cn)
       S.inv = mk3(1.0f / S.d.x, 1.0f / S.d.y, 1.0f / S.d.z);
       S.limit = length(bd);
     }
-  } else if (S.li < nlights && S.has_reflect) {
-    // every light's shadow ray has been started (here or by a helper lane): the reflection ray is the last one
-    S.li = nlights;
+  } else if (S.li == nlights && S.has_reflect) {
     S.o = S.bo; S.d = S.rdir; S.bounce = S.Hbounce - 1;
     S.inv = mk3(1.0f / S.d.x, 1.0f / S.d.y, 1.0f / S.d.z);
     S.limit = INFINITY;
     S.shadow = false;
   } else {
-    // nothing left to start: the batch is complete once the helper lanes (if any) have reported
     go = false;
-    S.li = nlights + 1;
-    if ((S.hx >> 8) == 0) S.batch_pending = false;
+    S.batch_pending = false;
     S.shadow = false;
     S.trav = false;
   }
@@ -390,7 +376,6 @@ MIRT_DEV int advance_core(const RenderArgs& a, Lane& S, Counters& cn, const long
       S.bo = S.Hp + S.Hn * EPSILON;
       S.occl = 0ull;
       S.li = -1;
-      S.hx = 0;
       S.batch_pending = true;
       S.state = ST_BATCH;
       micro = M_BATCH;

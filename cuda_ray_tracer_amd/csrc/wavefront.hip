@@ -133,7 +133,7 @@ __global__ void __launch_bounds__(SBLOCK, MIRT_WF_SHADE_WAVES) wf_shade_kernel(c
   S.Hbounce = 0; S.Hior = 1.458f; S.Hrough = 0.0f; S.HtransNZ = false;
   S.wt = mk3(1, 1, 1); S.wD = mk3(0, 0, 0); S.pn = mk3(0, 0, 0);
   S.pc = 0; S.refr_bounce = 0; S.gi_n = 0; S.state = ST_PRIMARY;
-  S.bo = mk3(0, 0, 0); S.rdir = mk3(0, 0, 1); S.li = 0; S.hx = 0; S.occl = 0ull; S.batch_pending = false; S.has_reflect = false;
+  S.bo = mk3(0, 0, 0); S.rdir = mk3(0, 0, 1); S.li = 0; S.occl = 0ull; S.batch_pending = false; S.has_reflect = false;
   S.o = mk3(0, 0, 0); S.d = mk3(0, 0, 1); S.inv = mk3(0, 0, 1); S.bounce = 0; S.limit = INFINITY; S.shadow = false;
   S.tplane = INFINITY; S.plane_id = -1; S.trav = false;
   S.cur = REF_NONE; S.tos = REF_NONE; S.sp = 0; S.tbest = INFINITY; S.refbest = REF_NONE;
