@@ -210,6 +210,27 @@ def test_two_million_primitive_build_matches_oracle():
     o.close()
 
 
+def test_full_size_frame_equals_its_eight_stripe_sets(gpu_scenes):
+    """BASELINE config 3 at full size, through a size-independent property: the whole 1920x1080 frame at 16 spp (256-sample
+    chunks, longest-first order from the first render applied in the second) against the same frame rendered as the
+    eight interleaved stripe sets an 8-GPU job uses (64-sample chunks) and re-interleaved -- byte for byte."""
+    stl, raw = gpu_scenes("tenthousand")
+    w, h, spp = 1920, 1080, 16
+    whole = torch.zeros(w * h * 4, dtype=torch.uint8, device="cuda")
+    for _ in range(2):                      # second pass: the chunk order measured by the first is in use
+        m.render(whole, w, h, spp, raw)
+    frame = torch.zeros(w * h * 4, dtype=torch.uint8, device="cuda")
+    for part in range(8):
+        p = api.render_params(w, h, spp, 4, 8, part)
+        buf = torch.zeros(api.num_pixels(p) * 4, dtype=torch.uint8, device="cuda")
+        m.render(buf, w, h, spp, raw, params=p)
+        api.scatter_part(p, buf, frame)
+    torch.cuda.synchronize()
+    assert torch.equal(whole, frame)
+    img = whole.cpu().numpy().reshape(h, w, 4)
+    assert img[..., 3].max() == 255 and 0 < int((img[..., 3] == 0).sum()) < w * h      # sky and geometry both present
+
+
 def test_frames_in_flight_and_chunk_order_do_not_change_pixels(gpu_scenes):
     """Four frames overlapped on four streams (each uses its own workspace set), rendered repeatedly so that later frames
     run with a longest-first chunk order measured on earlier ones: every frame must be byte-identical."""
