@@ -554,7 +554,17 @@ int render(MirtScene* sc, const MirtRenderParams* p, void* d_rgba8, void* d_rgba
   if (!blocks_cached) blocks_cached = grid_blocks(sc->device);
   long long want_blocks = (nsamples + TRACE_BLOCK - 1) / TRACE_BLOCK;
   int blocks = (int)(want_blocks < blocks_cached ? want_blocks : blocks_cached);
-  if (const char* e = getenv("MIRT_TRACE_WAVES")) { const int k = atoi(e); if (k >= 1 && k < blocks) blocks = k; }   // experiments
+  // A small frame (one GPU's stripe set of an 8-GPU job) rendered while another frame is in flight gets half the grid:
+  // every wave ends with a drain -- its last samples, few live lanes, 0.5-2.5 ms -- during which it holds its slot, and
+  // with two half-grid frames resident at a time there are half as many drains per frame (1/8 of 1080p x 16: 5.8 -> 5.4
+  // ms per frame; no gain from 1/4 of a frame up, a loss for a frame rendered alone).
+  if (!count && blocks == blocks_cached && nsamples < 20ll * blocks_cached * TRACE_BLOCK) {
+    for (int i = 0; i < MIRT_MAX_FRAMES; ++i) {
+      const RenderCtx& c = sc->ctx[i];
+      if (c.used && hipEventQuery(c.ev3) == hipErrorNotReady) { blocks = blocks_cached / 2; break; }
+    }
+  }
+  if (const char* e = getenv("MIRT_TRACE_WAVES")) { const int k = atoi(e); if (k >= 1 && k <= blocks_cached) blocks = k; }   // experiments
   const size_t gthreads = (size_t)blocks * TRACE_BLOCK;
 
   // this frame's context; wait for the frame that used it MIRT_MAX_FRAMES renders ago
