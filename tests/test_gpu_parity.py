@@ -121,6 +121,38 @@ def test_full_size_stripes_match_oracle(name, spp, gpu_scenes, oracle_scenes):
     check_image(gu8, gf, ref)
 
 
+def test_config4_redchair_4k_64spp_stripes_match_oracle(gpu_scenes, oracle_scenes):
+    """BASELINE config 4 (redchair.txt 3840x2160 at 64 spp): two 2-row stripes of the full-size frame against the oracle."""
+    stl, raw = gpu_scenes("redchair")
+    w, h, spp, rows = 3840, 2160, 64, 2
+    parts = h // rows // 2          # 540 parts -> part k owns stripes k and k+540
+    part = 333
+    gu8, gf = gpu_render(raw, w, h, spp, stripe_rows=rows, num_parts=parts, part=part)
+    o = oracle_scenes("redchair")
+    refs = [o.render(w, h, spp, tile=(0, (part + j * parts) * rows, w, rows), flags=ol.FLAG_ANYHIT_SHADOW, nthreads=8) for j in range(2)]
+    ref = dict(f32=np.concatenate([r["f32"].reshape(-1, 4) for r in refs]), u8=np.concatenate([r["u8"].reshape(-1, 4) for r in refs]))
+    check_image(gu8, gf, ref)
+
+
+def test_config5_two_million_primitives_4k_256spp_stripe_matches_oracle():
+    """BASELINE config 5 (1 M spheres + 1 M triangles, 3840x2160 at 256 spp): one row of the full-size frame -- pixels, and
+    the ray / node / primitive counters with `==`."""
+    stl = m.syntheticScene(1_000_000, 1_000_000, seed=1234)
+    raw = m.initRawConfigFromStl(stl, 0)
+    m.build_lbvh_karas(raw)
+    w, h, spp, rows = 3840, 2160, 256, 1
+    parts, part = h, 1201
+    gu8, gf = gpu_render(raw, w, h, spp, stripe_rows=rows, num_parts=parts, part=part, counters=True)
+    st = raw.stats()
+    o = ol.OracleScene(ol.ArrayScene(stl), bounds_mode=0)
+    ref = o.render(w, h, spp, tile=(0, part, w, rows), flags=ol.FLAG_ANYHIT_SHADOW, nthreads=8)
+    check_image(gu8, gf, ref)
+    for k in ("samples", "rays", "shadow_rays", "internal_visits", "sphere_tests", "tri_tests", "mat_fetches", "max_stack"):
+        assert st[k] == ref["stats"][k], (k, st[k], ref["stats"][k])
+    raw.close()
+    o.close()
+
+
 def test_stripe_partition_is_bit_identical_to_whole_frame(gpu_scenes):
     """Tile-split invariance: any partition gives the same bytes."""
     stl, raw = gpu_scenes("tenthousand")
