@@ -563,7 +563,7 @@ int render(MirtScene* sc, const MirtRenderParams* p, void* d_rgba8, void* d_rgba
   if (!count && blocks == blocks_cached && nsamples < 20ll * blocks_cached * TRACE_BLOCK) {
     for (int i = 0; i < MIRT_MAX_FRAMES; ++i) {
       const RenderCtx& c = sc->ctx[i];
-      if (c.used && hipEventQuery(c.ev3) == hipErrorNotReady) { blocks = blocks_cached / 2; break; }
+      if (c.used && c.stream != stream && hipEventQuery(c.ev3) == hipErrorNotReady) { blocks = blocks_cached / 2; break; }   // (a frame on this same stream does not overlap)
     }
   }
   if (const char* e = getenv("MIRT_TRACE_WAVES")) { const int k = atoi(e); if (k >= 1 && k <= blocks_cached) blocks = k; }   // experiments
@@ -764,7 +764,7 @@ int render(MirtScene* sc, const MirtRenderParams* p, void* d_rgba8, void* d_rgba
   } else cx.order_key = -1;
   ++cx.uses;
   MIRT_HIP(hipEventRecord(cx.ev3, stream));
-  cx.used = true; cx.counted = count; cx.timed = false; sc->last = &cx;
+  cx.used = true; cx.counted = count; cx.timed = false; cx.stream = stream; sc->last = &cx;
   return MIRT_OK;
 }
 

@@ -107,6 +107,7 @@ struct RenderCtx {
   float* pending = nullptr; size_t pending_cap = 0;
   unsigned long long* counters = nullptr;  // device: [0..7] MirtStats counters, [8] work counter
   unsigned long long* prof = nullptr;      // diagnostic stamps (MIRT_PROF)
+  hipStream_t stream = nullptr;            // the stream this context's latest frame was issued on
   RenderArgs* args_dev = nullptr;          // this frame's RenderArgs in device memory
   hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr, ev3 = nullptr;   // render start / trace start / trace end / render end
   bool used = false, counted = false, timed = true;
