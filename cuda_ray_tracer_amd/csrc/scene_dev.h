@@ -80,6 +80,7 @@ struct HotArgs {
   const LightDev* bulbs; int num_bulbs;
   uint32_t* stack_spill;
   int lds_depth, refill_k, batch_k, drain_lanes;
+  int reps;                       // traversal steps per pass through the loop header
   int leaf_k;                     // primitive tests are held back until this many lanes of the wave have one pending
   unsigned long long* prof;
 };

@@ -43,12 +43,44 @@ def analyze(defines=()):
             break
         if inside:
             body.append(l)
-    # the traversal loop is the last depth-2 loop of the kernel; its blocks carry "Header=<label> Depth=2" (inner loops: Depth=3)
-    hdr = re.findall(r"Header=(BB\d+_\d+) Depth=2", "\n".join(body))[-1]
+    # the traversal loop is the last depth-2 loop of the kernel: its blocks carry "in Loop: Header=<label> Depth=2", the
+    # blocks of its inner loops (plane loops, step loop) "Header=<inner> Depth=3", where <inner> is a loop header whose
+    # comment names <label> as its depth-2 parent
+    text = "\n".join(body)
+
+    def members(hdr):
+        inner = set()
+        for m in re.finditer(r"^\.L(BB\d+_\d+):((?:[^\n]*\n\s+;[^\n]*)*)", text, re.M):
+            if ("Parent Loop " + hdr + " Depth=2") in m.group(0) and "Inner Loop Header: Depth=3" in m.group(0):
+                inner.add(m.group(1))
+
+        def in_loop(l):
+            if ("Header=" + hdr + " Depth=2") in l or l.startswith(".L" + hdr + ":"):
+                return True
+            m = re.search(r"Header=(BB\d+_\d+) Depth=3", l)
+            if m and m.group(1) in inner:
+                return True
+            m = re.match(r"^\.L(BB\d+_\d+):", l)
+            return bool(m and m.group(1) in inner)
+        return in_loop
+
+    # the traversal loop: the depth-2 loop (with its inner loops) that pushes onto the LDS stack
+    in_loop = None
+    for hdr in dict.fromkeys(re.findall(r"Header=(BB\d+_\d+) Depth=2", text)):
+        f, cur, hit = members(hdr), None, False
+        for l in body:
+            if re.match(r"^\.LBB\d+_\d+:", l) or re.match(r"^; %bb", l):
+                cur = f(l)
+            elif cur and "ds_write_b32" in l:
+                hit = True
+                break
+        if hit:
+            in_loop = f
+    assert in_loop is not None, "traversal loop not found"
     cnt, spills, cur, pos = collections.Counter(), [], None, 0
     for l in body:
         if re.match(r"^\.LBB\d+_\d+:", l) or re.match(r"^; %bb", l):
-            cur = "loop" if (("Header=" + hdr + " Depth=2") in l or l.startswith(".L" + hdr + ":")) else None
+            cur = "loop" if in_loop(l) else None
             continue
         t = l.strip()
         if not t or t.startswith(";") or t.startswith(".") or cur != "loop":
