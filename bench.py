@@ -7,8 +7,8 @@ One step = one frame of the hot path (trace + resolve, scene and BVH resident in
 BASELINE.json's headline workload, `tenthousand.txt` at 1920x1080, 16 samples per pixel.  With N > 1 (launched by
 torch.distributed.run, one process per GPU) the frame is cut into interleaved row stripes, every rank renders its
 stripes with a replicated BVH, and the 8-bit framebuffer is gathered to rank 0 over RCCL and re-interleaved there; the
-total work per frame is fixed ("strong" scaling).  Consecutive frames are kept in flight on alternating streams (two on
-one GPU, three per GPU on several; `--serial` for one): the drain of a frame is a single lane's bounce chain, and the next
+total work per frame is fixed ("strong" scaling).  Consecutive frames are kept in flight on alternating streams (two per
+GPU; `--serial` for one): the drain of a frame is a single lane's bounce chain, and the next
 frame's workgroups use the CUs it frees.  Rank 0 prints ONE JSON line.
 
 value        = rays of the whole frame / max-over-ranks wall time per frame  (Mrays/s; a ray = one hitNearest call with
@@ -126,7 +126,7 @@ def main():
     # Frames in flight: consecutive frames go to alternating streams, each with its own part buffer and (on rank 0) its own
     # gather buffers and frame, so the next frame's workgroups fill the CUs the draining frame frees (the drain of a frame
     # is one lane's 16-bounce chain, ~8 ms of latency).
-    nfl = args.frames_in_flight if args.frames_in_flight > 0 else (2 if pworld == 1 else 3)
+    nfl = args.frames_in_flight if args.frames_in_flight > 0 else 2       # 3 is ~3 % better over 24+ steps, worse over 10
     nfl = 1 if args.serial else max(1, min(4, nfl))
     streams = [torch.cuda.Stream(device=dev) for _ in range(nfl)]
     gatherers = [FrameGatherer(partition, prank, pworld, dev) for _ in range(nfl)]
