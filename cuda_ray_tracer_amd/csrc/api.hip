@@ -158,7 +158,7 @@ void mirt_scene_destroy(MirtScene* sc)
   hipDeviceSynchronize();
   hipFree(sc->heap); hipFree(sc->tri_verts); hipFree(sc->mats); hipFree(sc->refs_in);
   hipFree(sc->planes); hipFree(sc->suns); hipFree(sc->bulbs);
-  hipFree(sc->codes); hipFree(sc->order); hipFree(sc->child_l); hipFree(sc->child_r); hipFree(sc->parent); hipFree(sc->boxes);
+  hipFree(sc->codes); hipFree(sc->order); hipFree(sc->child_l); hipFree(sc->child_r); hipFree(sc->parent); hipFree(sc->boxes); hipFree(sc->build_ws);
   hipFree(sc->bounds_keys);
   for (int i = 0; i < mirt::MIRT_MAX_FRAMES; ++i) {
     mirt::RenderCtx& c = sc->ctx[i];

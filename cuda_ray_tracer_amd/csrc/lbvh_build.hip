@@ -373,6 +373,14 @@ int build_lbvh(MirtScene* sc, hipStream_t stream)
   sc->root_ref = REF_NONE;
   if (n == 0) { sc->built = true; sc->build_ms = 0.0f; return MIRT_OK; }   // main.cu:44: build skipped when there are no primitives
 
+  // sort / refit workspace: one allocation, made before the timed region and kept with the scene (a rebuild reuses it)
+  const int sblocks = (n + SORT_TILE - 1) / SORT_TILE;
+  const size_t wwords = 4 * (size_t)n + 256 * (size_t)sblocks + 256 + (size_t)(n > 1 ? n - 1 : 0);
+  if (sc->build_ws_words < wwords) {
+    (void)hipFree(sc->build_ws); sc->build_ws = nullptr; sc->build_ws_words = 0;
+    MIRT_HIP(hipMalloc(&sc->build_ws, sizeof(uint32_t) * wwords));
+    sc->build_ws_words = wwords;
+  }
   MIRT_HIP(hipEventRecord(sc->ev0, stream));
   // scene bounds
   static const uint32_t init_keys[6] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0u, 0u, 0u};
@@ -382,12 +390,9 @@ int build_lbvh(MirtScene* sc, hipStream_t stream)
   hipLaunchKernelGGL(prim_bounds_kernel, dim3(bgrid), dim3(BLOCK), 0, stream, sc->refs_in, sc->spheres, sc->tri_verts, n, sc->bounds_keys);
 
   // morton codes + stable sort
-  uint32_t *k0 = nullptr, *v0 = nullptr, *k1 = nullptr, *v1 = nullptr, *hist = nullptr, *totals = nullptr;
-  const int sblocks = (n + SORT_TILE - 1) / SORT_TILE;
-  MIRT_HIP(hipMalloc(&k0, sizeof(uint32_t) * n)); MIRT_HIP(hipMalloc(&v0, sizeof(uint32_t) * n));
-  MIRT_HIP(hipMalloc(&k1, sizeof(uint32_t) * n)); MIRT_HIP(hipMalloc(&v1, sizeof(uint32_t) * n));
-  MIRT_HIP(hipMalloc(&hist, sizeof(uint32_t) * 256 * (size_t)sblocks));
-  MIRT_HIP(hipMalloc(&totals, sizeof(uint32_t) * 256));
+  uint32_t* const ws = sc->build_ws;
+  uint32_t *k0 = ws, *v0 = ws + (size_t)n, *k1 = ws + 2 * (size_t)n, *v1 = ws + 3 * (size_t)n;
+  uint32_t *hist = ws + 4 * (size_t)n, *totals = hist + 256 * (size_t)sblocks;
   hipLaunchKernelGGL(morton_kernel, dim3(nblk), dim3(BLOCK), 0, stream, sc->refs_in, sc->spheres, sc->tri_verts, n, sc->bounds_keys, k0, v0);
   uint32_t *ki = k0, *vi = v0, *ko = k1, *vo = v1;
   for (int pass = 0; pass < 4; ++pass) {
@@ -401,9 +406,8 @@ int build_lbvh(MirtScene* sc, hipStream_t stream)
   MIRT_HIP(hipMemcpyAsync(sc->codes, ki, sizeof(uint32_t) * n, hipMemcpyDeviceToDevice, stream));
   MIRT_HIP(hipMemcpyAsync(sc->order, vi, sizeof(uint32_t) * n, hipMemcpyDeviceToDevice, stream));
 
-  uint32_t* arrived = nullptr;
+  uint32_t* arrived = totals + 256;
   if (n > 1) {
-    MIRT_HIP(hipMalloc(&arrived, sizeof(uint32_t) * (n - 1)));
     MIRT_HIP(hipMemsetAsync(arrived, 0, sizeof(uint32_t) * (n - 1), stream));
     MIRT_HIP(hipMemsetAsync(sc->parent, 0xff, sizeof(int) * (2 * (size_t)n - 1), stream));
     const int kblk = (n - 1 + BLOCK - 1) / BLOCK;
@@ -427,7 +431,6 @@ int build_lbvh(MirtScene* sc, hipStream_t stream)
   } else {
     sc->root_ref = 0;
   }
-  (void)hipFree(k0); (void)hipFree(v0); (void)hipFree(k1); (void)hipFree(v1); (void)hipFree(hist); (void)hipFree(totals); (void)hipFree(arrived);
   sc->built = true;
   return MIRT_OK;
 }

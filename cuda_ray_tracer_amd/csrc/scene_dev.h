@@ -152,6 +152,7 @@ struct MirtScene {
   float4* nodes = nullptr;              // packed [N-1][4]; start of the record heap [nodes | spheres | tris | pad]
   unsigned char* heap = nullptr;
   uint32_t sph_base = 0, tri_base = 0;
+  uint32_t* build_ws = nullptr; size_t build_ws_words = 0;   // LBVH build workspace (sort buffers, histograms, arrival counters)
   uint32_t* bounds_keys = nullptr;      // [6] ordered-uint min xyz, max xyz
   uint32_t root_ref = mirt::REF_NONE;
   bool built = false;
