@@ -53,7 +53,7 @@ __global__ void __launch_bounds__(TRACE_BLOCK, MIRT_WAVES_PER_SIMD) trace_kernel
   unsigned long long pf_S = 0, pf_T = 0, pf_iters = 0, pf_active = 0, pf_Sent = 0, pf_Slanes = 0, pf_Bent = 0, pf_Blanes = 0, pf_leaf = 0, pf_node = 0;
   const unsigned long long pf_t0 = PROF ? clock64() : 0;
   const unsigned long long pf_w0 = PROF ? wall_clock64() : 0;   // 100 MHz
-  unsigned long long pf_adv = 0, pf_adv_it = 0, pf_init = 0;
+  unsigned long long pf_adv = 0, pf_adv_it = 0, pf_init = 0, pf_Bcyc = 0;
   unsigned long long pf_tx = 0, pf_xit = 0, pf_xS = 0, pf_dit = 0, pf_xact = 0;
   __shared__ __attribute__((aligned(16))) unsigned char lds_raw[STACK_LDS * TRACE_BLOCK * 4];     // traversal stacks: STACK_LDS x TRACE_BLOCK words
   // The random-number state (8 words per lane) is only touched in the shade phase: it lives here during traversal so
@@ -171,7 +171,9 @@ __global__ void __launch_bounds__(TRACE_BLOCK, MIRT_WAVES_PER_SIMD) trace_kernel
       // lanes whose batch ray finished move on to the next ray of their batch (cheap; done in groups)
       if (bm != 0 && (__popcll(bm) >= h.batch_k || tm == 0 || drain)) {
         if (PROF) { pf_Bent++; pf_Blanes += __popcll(bm); }
+        const unsigned long long pf_b0 = PROF ? clock64() : 0;
         if (!S.trav && S.batch_pending) batch_next<COUNT>(h, S, cn);
+        if (PROF) pf_init += 0, pf_Bcyc += clock64() - pf_b0;
       }
       if (PROF && exhausted) { pf_xit++; pf_xact += __popcll(__ballot(S.trav)); if (drain) pf_dit++; }
       if (PROF) { pf_iters++; pf_active += __popcll(__ballot(S.trav)); pf_leaf += __popcll(__ballot(S.trav && (S.cur & REF_LEAF))); }
@@ -282,7 +284,7 @@ __global__ void __launch_bounds__(TRACE_BLOCK, MIRT_WAVES_PER_SIMD) trace_kernel
     atomicAdd(&h.prof[0], tot); atomicAdd(&h.prof[1], pf_S); atomicAdd(&h.prof[2], pf_T); atomicAdd(&h.prof[3], pf_iters);
     atomicAdd(&h.prof[4], pf_active); atomicAdd(&h.prof[5], pf_Sent); atomicAdd(&h.prof[6], pf_Slanes); atomicAdd(&h.prof[7], pf_Bent);
     atomicAdd(&h.prof[8], pf_Blanes); atomicAdd(&h.prof[9], pf_leaf); atomicAdd(&h.prof[10], 1ull);
-    atomicAdd(&h.prof[16 + 3 * (size_t)gridDim.x * (TRACE_BLOCK / 64)], pf_adv); atomicAdd(&h.prof[17 + 3 * (size_t)gridDim.x * (TRACE_BLOCK / 64)], pf_adv_it); atomicAdd(&h.prof[18 + 3 * (size_t)gridDim.x * (TRACE_BLOCK / 64)], pf_init);
+    atomicAdd(&h.prof[16 + 3 * (size_t)gridDim.x * (TRACE_BLOCK / 64)], pf_adv); atomicAdd(&h.prof[17 + 3 * (size_t)gridDim.x * (TRACE_BLOCK / 64)], pf_adv_it); atomicAdd(&h.prof[18 + 3 * (size_t)gridDim.x * (TRACE_BLOCK / 64)], pf_init); atomicAdd(&h.prof[19 + 3 * (size_t)gridDim.x * (TRACE_BLOCK / 64)], pf_Bcyc);
     atomicAdd(&h.prof[11], pf_xit); atomicAdd(&h.prof[12], pf_xS); atomicAdd(&h.prof[14], pf_dit); atomicAdd(&h.prof[15], pf_xact);
     // per wave: start, queue-empty and exit times (100 MHz wall clock)
     unsigned long long* w = h.prof + 16 + 3 * (size_t)blockIdx.x * (TRACE_BLOCK / 64) + 3 * (tid >> 6);
@@ -710,8 +712,8 @@ int render(MirtScene* sc, const MirtRenderParams* p, void* d_rgba8, void* d_rgba
     if (prof) {
       const size_t nwaves = (size_t)blocks * (TRACE_BLOCK / 64);
       if (cx.prof) { hipFree(cx.prof); cx.prof = nullptr; }
-      MIRT_HIP(hipMalloc(&cx.prof, (19 + 3 * nwaves) * sizeof(unsigned long long)));
-      MIRT_HIP(hipMemsetAsync(cx.prof, 0, (19 + 3 * nwaves) * sizeof(unsigned long long), stream));
+      MIRT_HIP(hipMalloc(&cx.prof, (20 + 3 * nwaves) * sizeof(unsigned long long)));
+      MIRT_HIP(hipMemsetAsync(cx.prof, 0, (20 + 3 * nwaves) * sizeof(unsigned long long), stream));
       a.prof = cx.prof; h.prof = cx.prof;
     }
     MIRT_HIP(hipMemcpyAsync(cx.args_dev, &a, sizeof(RenderArgs), hipMemcpyHostToDevice, stream));
@@ -724,10 +726,11 @@ int render(MirtScene* sc, const MirtRenderParams* p, void* d_rgba8, void* d_rgba
               hh[10], (double)hh[0] / hh[10], 100.0 * hh[1] / hh[0], 100.0 * hh[2] / hh[0], (double)hh[3] / hh[10], (double)hh[4] / (hh[3] ? hh[3] : 1), (double)hh[9] / (hh[3] ? hh[3] : 1),
               (double)hh[5] / hh[10], (double)hh[6] / (hh[5] ? hh[5] : 1), (double)hh[7] / hh[10], (double)hh[8] / (hh[7] ? hh[7] : 1));
       {
-        unsigned long long ad[3];
+        unsigned long long ad[4];
         MIRT_HIP(hipMemcpy(ad, cx.prof + 16 + 3 * (size_t)blocks * (TRACE_BLOCK / 64), sizeof(ad), hipMemcpyDeviceToHost));
         fprintf(stderr, "[mirt prof] shade phase: %.1f%% of it in the advance/batch loop (%.2f passes per entry), %.1f%% in init_sample, the rest in the chunk hand-out and the RNG / state moves\n",
                 100.0 * ad[0] / (hh[1] ? hh[1] : 1), (double)ad[1] / (hh[5] ? hh[5] : 1), 100.0 * ad[2] / (hh[1] ? hh[1] : 1));
+        fprintf(stderr, "[mirt prof] traversal phase: %.1f%% of it in the batch transitions of the loop header (batch_next + start_ray)\n", 100.0 * ad[3] / (hh[2] ? hh[2] : 1));
       }
       fprintf(stderr, "[mirt prof] after the queue is empty, per wave: %.0f iterations (%.1f lanes traversing, %.0f in drain mode), %.1f shade-phase entries\n",
               (double)hh[11] / hh[10], (double)hh[15] / (hh[11] ? hh[11] : 1), (double)hh[14] / hh[10], (double)hh[12] / hh[10]);
