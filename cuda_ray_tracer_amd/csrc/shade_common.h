@@ -171,10 +171,13 @@ MIRT_DEV void start_ray(const Args& a, Lane& S, Counters& cn)
   if (!HAVE_INV) S.inv = mk3(1.0f / S.d.x, 1.0f / S.d.y, 1.0f / S.d.z);
   float tplane = INFINITY;
   int plane_id = -1;
+  // (the planes are the same for every lane and never written by a kernel: read them through the constant address space,
+  // i.e. with scalar loads, not through the per-lane address unit)
+  typedef const PlaneDev __attribute__((address_space(4))) * ConstPlanes;
+  const ConstPlanes planes = (ConstPlanes)(unsigned long long)a.planes;
   for (int i = 0; i < a.num_planes; ++i) {
-    const PlaneDev& pl = a.planes[i];
-    const f3 pnor = mk3(pl.nx, pl.ny, pl.nz);
-    const float t = dot(mk3(pl.px, pl.py, pl.pz) - S.o, pnor) / dot(S.d, pnor);
+    const f3 pnor = mk3(planes[i].nx, planes[i].ny, planes[i].nz);
+    const float t = dot(mk3(planes[i].px, planes[i].py, planes[i].pz) - S.o, pnor) / dot(S.d, pnor);
     if (t <= 1e-6f) continue;
     if (t < tplane && t > EPSILON) { tplane = t; plane_id = i; }
   }
