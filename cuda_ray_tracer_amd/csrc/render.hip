@@ -6,9 +6,14 @@
 //                 (the reference's mutually recursive shading functions turned into an explicit ray-tree walk) around ONE
 //                 shared BVH traversal loop, so that primary, shadow, reflection, refraction and GI rays of different
 //                 lanes are traversed together.  Traversal stack: 32 entries per lane in LDS ([entry][lane], conflict
-//                 free), spilling to global memory above that.  Nodes are 64-byte two-child records.
-// resolve_kernel  per pixel: sum the samples in the reference's xor-butterfly order (draw.cu:181-189), mean, sRGB,
-//                 quantise (draw.cu:129-132 for spp <= 1, draw.cu:9-11,202-205 otherwise).
+//                 free), spilling to global memory above that.  Nodes are 64-byte two-child records.  A workgroup
+//                 is one wave; the loop header (who traverses, who waits, is the wave draining, are enough primitive
+//                 tests pending) runs once per four traversal steps; only what the loop touches is passed by value.
+// resolve_tree_kernel / resolve_kernel
+//                 per pixel: sum the samples in the reference's xor-butterfly order (draw.cu:181-189), mean, sRGB,
+//                 quantise (draw.cu:129-132 for spp <= 1, draw.cu:9-11,202-205 otherwise); one lane per sample when
+//                 the butterfly fits a wave, one thread per pixel otherwise.
+// order_kernel    sorts the frame's sample chunks by their measured cost: later frames hand them out longest first.
 //
 // The ray tree is evaluated top-down (every ray carries the product of the mixing weights above it) instead of the
 // reference's bottom-up recursion; geometry and random-number consumption are identical, colours agree to rounding.
