@@ -48,9 +48,11 @@ def _worker(rank, world, port, out_path):
 
 
 @pytest.mark.timeout(300)
-def test_two_rank_gloo_frame_gather_equals_whole_frame(tmp_path):
+@pytest.mark.parametrize("world", [2, 3])
+def test_gloo_frame_gather_equals_whole_frame(world, tmp_path):
+    """7 stripes of 4 rows (the last one 3 rows) over 2 or 3 ranks: ragged parts, padded buffers."""
     out = str(tmp_path / "frame.npy")
-    mp.spawn(_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), out), nprocs=world, join=True)
     got = np.load(out).reshape(H, W, 4)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_lib
