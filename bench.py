@@ -83,6 +83,7 @@ def main():
                     help="diagnostic: one process renders only part 0 of an N-way stripe partition (what one rank of N does, without "
                          "the gather); the line then reports that share's rays and time, not a whole job")
     ap.add_argument("--png", default=None, help="write the last frame here (rank 0)")
+    ap.add_argument("--headline-only", action="store_true", help="skip the extra configurations (profiling runs)")
     args = ap.parse_args()
 
     import torch

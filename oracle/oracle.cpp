@@ -85,6 +85,12 @@ typedef struct {
 
 #define ORC_FLAG_ANYHIT_SHADOW 1u   /* shadow rays stop at the first occluder (same boolean as draw.cu:347-352,365-370) */
 #define ORC_FLAG_NORMAL_ZYX    2u   /* evaluate the three standerdD() arguments right-to-left (draw.cu:335-337 is unspecified) */
+/* experiment switches of the ordered traversal (traverse_x) */
+#define ORC_X_NEAR   16u   /* descend the nearer child first */
+#define ORC_X_CULL   32u   /* entry distance on the stack, re-tested on pop */
+#define ORC_X_PLANE  64u   /* closest-hit rays start with t_max = the plane hit distance */
+#define ORC_X_LE    128u   /* box rule t_enter <= t_max instead of < */
+#define ORC_X_ANY    (ORC_X_NEAR | ORC_X_CULL | ORC_X_PLANE | ORC_X_LE)
 
 /* ------------------------------------------------------------------------------------------------ */
 /* vec3 / RGB (vec3.cuh:7-107, struct.cuh:11-62)                                                     */
@@ -277,6 +283,10 @@ struct Scene {
   std::vector<ONode> nodes;         /* internal [0,N-2], leaves [N-1,2N-2] */
   float smin[3], smax[3];
   bool built;
+  std::vector<int> rfirst, rlast;   /* sorted-leaf range of every internal node (Karras) */
+  int collapse_k = 1;               /* experiment: subtrees with at most this many primitives are tested as one leaf */
+  int collapse_mixed = 1;
+  std::vector<uint8_t> collapsed;   /* per internal node */
 };
 
 struct AABB { float xmin, xmax, ymin, ymax, zmin, zmax; };
@@ -441,6 +451,7 @@ static int build(Scene& sc, int bounds_mode)
 
   const int total = 2 * N - 1;
   sc.nodes.assign(total, ONode());
+  sc.rfirst.assign(N > 1 ? N - 1 : 0, 0); sc.rlast.assign(N > 1 ? N - 1 : 0, 0);
   std::vector<int> parent(total, -1);
   const uint32_t leaf_base = (uint32_t)(N - 1);
   /* initialize_leaf_nodes_kernel, lbvh_builder.cu:59-71 */
@@ -450,6 +461,7 @@ static int build(Scene& sc, int bounds_mode)
   for (int i = 0; i < N - 1; ++i) {
     int first, last;
     determine_range(cd, (uint32_t)N, i, &first, &last);
+    sc.rfirst[i] = first; sc.rlast[i] = last;
     if (first > last) continue;
     const int split = find_split(cd, first, last, (uint32_t)N);
     if (split < first || split >= last) {
@@ -630,6 +642,78 @@ static Obj traverse(Ctx& cx, const Ray& ray, float initial_t_max, bool early, fl
   return best;
 }
 
+static inline bool hit_aabb_t(const ONode& b, const V3& o, const V3& inv, float tmin, float tmax, float* te, bool le)
+{
+  float tx1 = (b.xmin - o.x) * inv.x, tx2 = (b.xmax - o.x) * inv.x;
+  float tnx = fminf(tx1, tx2), tfx = fmaxf(tx1, tx2);
+  float ty1 = (b.ymin - o.y) * inv.y, ty2 = (b.ymax - o.y) * inv.y;
+  float tny = fminf(ty1, ty2), tfy = fmaxf(ty1, ty2);
+  float tz1 = (b.zmin - o.z) * inv.z, tz2 = (b.zmax - o.z) * inv.z;
+  float tnz = fminf(tz1, tz2), tfz = fmaxf(tz1, tz2);
+  float t_enter = fmaxf(fmaxf(tnx, tny), tnz);
+  float t_exit = fminf(fminf(tfx, tfy), tfz);
+  *te = t_enter;
+  return t_enter < t_exit && (le ? t_enter <= tmax : t_enter < tmax) && t_exit > tmin;
+}
+
+/* Experimental ordered traversal: same closest hit as traverse() (ties in t go to the smaller sorted-leaf index, which is
+ * what the left-first walk finds first), fewer node visits. */
+static Obj traverse_x(Ctx& cx, const Ray& ray, float initial_t_max, bool early, float stop_below)
+{
+  const Scene& sc = *cx.sc;
+  const uint32_t fl = cx.flags;
+  Obj best = obj_none();
+  best.distance = initial_t_max;
+  float tmax = initial_t_max;
+  uint32_t best_leaf = 0xffffffffu;
+  if (sc.nodes.empty()) return best;
+  V3 inv = mk(1.0f / ray.dir.x, 1.0f / ray.dir.y, 1.0f / ray.dir.z);
+  const float tmin = 0.0001f;
+  const uint32_t N = (uint32_t)sc.refs.size();
+  uint32_t stack[64]; float stack_t[64];
+  int sp = 0;
+  uint32_t cur = 0;
+  bool have = true;
+  while (have) {
+    const ONode& node = sc.nodes[cur];
+    cx.st.node_iters++;
+    uint32_t lf = 0, ll = 0; bool leaf = false;
+    if (node.count > 0) { leaf = true; lf = ll = node.prim_offset; }
+    else if (cur < N - 1 && !sc.collapsed.empty() && sc.collapsed[cur]) { leaf = true; lf = (uint32_t)sc.rfirst[cur]; ll = (uint32_t)sc.rlast[cur]; }
+    if (leaf) {
+      for (uint32_t k = lf; k <= ll; ++k) {
+        const OPrimRef& ref = sc.refs[k];
+        Obj h;
+        if (ref.type == 0) { h = check_sphere(cx, ray, ref.id); cx.st.sphere_tests++; }
+        else { h = check_triangle(cx, ray, ref.id); cx.st.tri_tests++; }
+        if (h.isHit && h.distance > 1e-6f && (h.distance < tmax || (h.distance == tmax && k < best_leaf))) {
+          tmax = h.distance; best = h; best_leaf = k;
+          if (early && best.distance < stop_below) return best;
+        }
+      }
+    } else {
+      cx.st.internal_visits++;
+      uint32_t l = node.left, r = node.right;
+      float tl, tr;
+      bool hl = hit_aabb_t(sc.nodes[l], ray.eye, inv, tmin, tmax, &tl, fl & ORC_X_LE);
+      bool hr = hit_aabb_t(sc.nodes[r], ray.eye, inv, tmin, tmax, &tr, fl & ORC_X_LE);
+      if (hl && hr) {
+        const bool swap = (fl & ORC_X_NEAR) && tr < tl;
+        cur = swap ? r : l;
+        if (sp < 64) { stack[sp] = swap ? l : r; stack_t[sp] = swap ? tl : tr; ++sp; if ((uint64_t)sp > cx.st.max_stack) cx.st.max_stack = (uint64_t)sp; }
+        continue;
+      } else if (hl) { cur = l; continue; }
+      else if (hr) { cur = r; continue; }
+    }
+    have = false;
+    while (sp > 0) {
+      --sp;
+      if (!(fl & ORC_X_CULL) || ((fl & ORC_X_LE) ? stack_t[sp] <= tmax : stack_t[sp] < tmax)) { cur = stack[sp]; have = true; break; }
+    }
+  }
+  return best;
+}
+
 /* checkPlane, draw.cu:581-615 */
 static Obj check_plane(const Ctx& cx, const Ray& ray)
 {
@@ -660,8 +744,16 @@ static Obj hit_nearest(Ctx& cx, const Ray& ray, bool count_mat = true)
 {
   if (ray.bounce == 0) return obj_none();
   cx.st.rays++;
-  Obj b = traverse(cx, ray, INFINITY, false, -1.0f);
-  Obj p = check_plane(cx, ray);
+  Obj b, p;
+  if (cx.flags & ORC_X_ANY) {
+    p = check_plane(cx, ray);
+    const bool bound = (cx.flags & ORC_X_PLANE) && p.isHit;
+    b = traverse_x(cx, ray, bound ? p.distance : INFINITY, false, -1.0f);
+    if (bound && !(b.distance < p.distance)) b.isHit = false;
+  } else {
+    b = traverse(cx, ray, INFINITY, false, -1.0f);
+    p = check_plane(cx, ray);
+  }
   Obj r;
   if (b.isHit && p.isHit) r = (b.distance < p.distance) ? b : p;
   else if (b.isHit) r = b;
@@ -684,7 +776,7 @@ static bool occluded(Ctx& cx, const Ray& ray, float limit)
   cx.st.rays++;
   Obj p = check_plane(cx, ray);
   if (p.isHit && p.distance < limit) return true;
-  Obj b = traverse(cx, ray, INFINITY, true, limit);
+  Obj b = (cx.flags & ORC_X_ANY) ? traverse_x(cx, ray, INFINITY, true, limit) : traverse(cx, ray, INFINITY, true, limit);
   return b.isHit && b.distance < limit;
 }
 
@@ -1017,6 +1109,21 @@ void* orc_scene_create(const OSceneDesc* d)
 void orc_scene_destroy(void* h) { delete (Scene*)h; }
 
 int orc_build_lbvh(void* h, int bounds_mode) { return build(*(Scene*)h, bounds_mode); }
+/* experiment: subtrees of at most k primitives (all of one type unless mixed) become one leaf of traverse_x */
+void orc_set_collapse(void* h, int k, int mixed)
+{
+  Scene& sc = *(Scene*)h;
+  const int N = (int)sc.refs.size();
+  sc.collapse_k = k; sc.collapse_mixed = mixed;
+  sc.collapsed.assign(N > 1 ? N - 1 : 0, 0);
+  for (int i = 0; i < N - 1; ++i) {
+    const int cnt = sc.rlast[i] - sc.rfirst[i] + 1;
+    if (cnt > k) continue;
+    bool ok = true;
+    if (!mixed) for (int j = sc.rfirst[i]; j <= sc.rlast[i]; ++j) if (sc.refs[j].type != sc.refs[sc.rfirst[i]].type) ok = false;
+    sc.collapsed[i] = ok;
+  }
+}
 int orc_num_nodes(void* h) { return (int)((Scene*)h)->nodes.size(); }
 void orc_get_nodes(void* h, ONode* out) { Scene* s = (Scene*)h; if (!s->nodes.empty()) memcpy(out, s->nodes.data(), s->nodes.size() * sizeof(ONode)); }
 void orc_get_codes(void* h, uint32_t* out) { Scene* s = (Scene*)h; if (!s->codes.empty()) memcpy(out, s->codes.data(), s->codes.size() * 4); }
