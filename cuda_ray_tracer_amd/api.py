@@ -59,7 +59,7 @@ class RenderParams(C.Structure):
 
 class Stats(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in ("samples", "rays", "shadow_rays", "internal_visits", "sphere_tests",
-                                          "tri_tests", "mat_fetches", "max_stack")] + \
+                                          "tri_tests", "mat_fetches", "max_stack", "overflow_events")] + \
                [("trace_kernel_ms", C.c_float), ("render_ms", C.c_float), ("build_ms", C.c_float), ("num_nodes", C.c_int32),
                 ("trace_kernel_ms_mean", C.c_float), ("frames_timed", C.c_int32)]
 
@@ -76,7 +76,7 @@ class TreeNode(C.Structure):
 EXPORTS = [
     "mirt_last_error", "mirt_version", "mirt_parse_scene_file", "mirt_parse_scene_text", "mirt_synthetic_scene",
     "mirt_host_scene_destroy", "mirt_host_scene_desc", "mirt_host_scene_filename", "mirt_scene_create",
-    "mirt_scene_destroy", "mirt_build_lbvh", "mirt_render_num_pixels", "mirt_render", "mirt_scatter_part",
+    "mirt_scene_destroy", "mirt_scene_set_option", "mirt_scene_get_option", "mirt_build_lbvh", "mirt_render_num_pixels", "mirt_render", "mirt_scatter_part",
     "mirt_get_stats", "mirt_get_tree", "mirt_probe_math", "mirt_probe_xorwow", "mirt_write_png",
 ]
 
@@ -108,6 +108,8 @@ def lib():
     L.mirt_scene_create.argtypes = [C.POINTER(SceneDesc), C.c_int, C.POINTER(C.c_void_p)]
     L.mirt_scene_destroy.argtypes = [C.c_void_p]
     L.mirt_scene_destroy.restype = None
+    L.mirt_scene_set_option.argtypes = [C.c_void_p, C.c_char_p, C.c_int]
+    L.mirt_scene_get_option.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(C.c_int)]
     L.mirt_build_lbvh.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_float)]
     L.mirt_render_num_pixels.argtypes = [C.POINTER(RenderParams)]
     L.mirt_render_num_pixels.restype = C.c_int64
@@ -217,9 +219,19 @@ class RawConfig:
             pass
 
     def stats(self):
+        """MirtStats as a dict.  Raises MirtError (status 6) when a capacity overflow was recorded during a render."""
         st = Stats()
         _check(lib().mirt_get_stats(self._h, C.byref(st)))
         return st.as_dict()
+
+    def set_option(self, name, value):
+        """mirt_scene_set_option: build options ("leaf_spheres", "bounds_as_shipped") take effect at the next build_lbvh_karas."""
+        _check(lib().mirt_scene_set_option(self._h, name.encode(), int(value)))
+
+    def get_option(self, name):
+        v = C.c_int(0)
+        _check(lib().mirt_scene_get_option(self._h, name.encode(), C.byref(v)))
+        return v.value
 
     def tree(self):
         """(nodes, codes, refs, bounds) in the reference's numbering -- for parity tests."""

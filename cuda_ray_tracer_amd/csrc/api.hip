@@ -3,7 +3,10 @@
 #include "host_scene.h"
 
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
+#include <new>
+#include <string>
 #include <vector>
 
 using namespace mirt;
@@ -29,14 +32,81 @@ void pack_mat(const MirtMaterials& m, float4* out)
   out[2] = make_float4(m.trans.b, m.ior, m.roughness, 0.0f);
 }
 
+struct OptionDesc { const char* name; int Options::*field; int lo, hi; };
+const OptionDesc OPTIONS[] = {
+  {"bounds_as_shipped", &Options::bounds_as_shipped, 0, 1},
+  {"traversal", &Options::traversal, 0, 2}, {"wavefront", &Options::wavefront, 0, 1},
+  {"stack_lds_depth", &Options::stack_lds_depth, -1, 64}, {"refill_k", &Options::refill_k, 1, 64}, {"batch_k", &Options::batch_k, 1, 64},
+  {"leaf_k", &Options::leaf_k, 1, 64}, {"reps", &Options::reps, 1, 8}, {"drain_lanes", &Options::drain_lanes, 0, 64},
+  {"chunk_shift", &Options::chunk_shift, 0, 12}, {"trace_waves", &Options::trace_waves, 0, 1 << 20}, {"sched", &Options::sched, 0, 1},
+  {"wf_pool", &Options::wf_pool, 256, 1 << 24}, {"wf_refill_k", &Options::wf_refill_k, 1, 64},
+};
+
+// MIRT_<NAME> (upper case) overrides an option's default; read once per scene, here
+void options_from_env(Options& o)
+{
+  for (const OptionDesc& d : OPTIONS) {
+    std::string env = "MIRT_";
+    for (const char* c = d.name; *c; ++c) env += (char)toupper(*c);
+    if (const char* e = getenv(env.c_str())) { const long v = atol(e); if (v >= d.lo && v <= d.hi) o.*(d.field) = (int)v; }
+  }
+}
+
+int scene_create(const MirtSceneDesc* d, int device, MirtScene** out);
+
 } // namespace
 
 extern "C" {
 
+int mirt_scene_set_option(MirtScene* sc, const char* name, int value)
+{
+  if (!sc || !name) { set_error("mirt_scene_set_option: null argument"); return MIRT_ERR_ARG; }
+  for (const OptionDesc& d : OPTIONS)
+    if (strcmp(d.name, name) == 0) {
+      if (value < d.lo || value > d.hi) { set_error(std::string("mirt_scene_set_option: value out of range for ") + name); return MIRT_ERR_ARG; }
+      sc->opt.*(d.field) = value;
+      return MIRT_OK;
+    }
+  set_error(std::string("mirt_scene_set_option: unknown option ") + name);
+  return MIRT_ERR_ARG;
+}
+
+int mirt_scene_get_option(const MirtScene* sc, const char* name, int* value)
+{
+  if (!sc || !name || !value) { set_error("mirt_scene_get_option: null argument"); return MIRT_ERR_ARG; }
+  for (const OptionDesc& d : OPTIONS)
+    if (strcmp(d.name, name) == 0) { *value = sc->opt.*(d.field); return MIRT_OK; }
+  set_error(std::string("mirt_scene_get_option: unknown option ") + name);
+  return MIRT_ERR_ARG;
+}
+
 int mirt_scene_create(const MirtSceneDesc* d, int device, MirtScene** out)
 {
+  // nothing may unwind across the C boundary (std::bad_alloc from the host-side staging vectors of a huge scene)
+  try {
+    return scene_create(d, device, out);
+  } catch (const std::bad_alloc&) {
+    set_error("mirt_scene_create: out of host memory");
+    return MIRT_ERR_ARG;
+  }
+}
+
+} // extern "C"
+
+namespace {
+
+int scene_create(const MirtSceneDesc* d, int device, MirtScene** out)
+{
   if (!d || !out) { set_error("mirt_scene_create: null argument"); return MIRT_ERR_ARG; }
-  if (d->num_prims != d->num_spheres + d->num_triangles) { set_error("mirt_scene_create: num_prims != num_spheres + num_triangles"); return MIRT_ERR_ARG; }
+  *out = nullptr;
+  if (d->num_spheres < 0 || d->num_triangles < 0 || d->num_prims < 0 || d->num_planes < 0 || d->num_suns < 0 || d->num_bulbs < 0) {
+    set_error("mirt_scene_create: negative count"); return MIRT_ERR_ARG;
+  }
+  if ((d->num_spheres > 0 && !d->spheres) || (d->num_triangles > 0 && !d->triangles) || (d->num_prims > 0 && !d->prim_refs) ||
+      (d->num_planes > 0 && !d->planes) || (d->num_suns > 0 && !d->suns) || (d->num_bulbs > 0 && !d->bulbs)) {
+    set_error("mirt_scene_create: a count is positive but its array is null"); return MIRT_ERR_ARG;
+  }
+  if ((long long)d->num_spheres + d->num_triangles != d->num_prims) { set_error("mirt_scene_create: num_prims != num_spheres + num_triangles"); return MIRT_ERR_ARG; }
   if (d->num_suns + d->num_bulbs > 64) { set_error("mirt_scene_create: more than 64 lights are not supported"); return MIRT_ERR_ARG; }
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
@@ -48,6 +118,7 @@ int mirt_scene_create(const MirtSceneDesc* d, int device, MirtScene** out)
 
   MirtScene* sc = new MirtScene();
   sc->device = device;
+  options_from_env(sc->opt);
   sc->d = *d;
   sc->N = d->num_prims; sc->Ns = d->num_spheres; sc->Nt = d->num_triangles;
   const int N = sc->N;
@@ -107,8 +178,8 @@ int mirt_scene_create(const MirtSceneDesc* d, int device, MirtScene** out)
 
   int rc = MIRT_OK;
   auto chk = [&](int r) { if (rc == MIRT_OK) rc = r; };
-  // record heap: [internal nodes 64 B each | spheres 16 B | triangles 48 B | 64 B pad] -- the traversal kernel addresses
-  // any record with one 32-bit byte offset
+  // record heap: [internal nodes 64 B each | primitive records in sorted order: sphere 16 B, triangle 48 B | 64 B pad] -- the
+  // traversal kernel addresses any record with one 32-bit byte offset.  The build fills it (lbvh_build.hip).
   {
     const size_t nodes_bytes = N > 1 ? 64 * (size_t)(N - 1) : 0;
     const size_t sph_bytes = 16 * (size_t)sc->Ns, tri_bytes = 48 * (size_t)sc->Nt;
@@ -117,24 +188,25 @@ int mirt_scene_create(const MirtSceneDesc* d, int device, MirtScene** out)
     hipError_t e = hipMalloc(&sc->heap, total);
     if (e == hipSuccess) e = hipMemset(sc->heap, 0, total);
     if (e != hipSuccess) { delete sc; return hip_fail(e, "hipMalloc(heap)", __FILE__, __LINE__); }
-    sc->sph_base = (uint32_t)nodes_bytes; sc->tri_base = (uint32_t)(nodes_bytes + sph_bytes);
+    sc->prim_base = (uint32_t)nodes_bytes;
     sc->nodes = reinterpret_cast<float4*>(sc->heap);
-    sc->spheres = reinterpret_cast<float4*>(sc->heap + sc->sph_base);
-    sc->tris = reinterpret_cast<float4*>(sc->heap + sc->tri_base);
-    if (sph_bytes) e = hipMemcpy(sc->spheres, spheres.data(), sph_bytes, hipMemcpyHostToDevice);
-    if (e == hipSuccess && tri_bytes) e = hipMemcpy(sc->tris, tris.data(), tri_bytes, hipMemcpyHostToDevice);
-    if (e != hipSuccess) { mirt_scene_destroy(sc); return hip_fail(e, "hipMemcpy(heap)", __FILE__, __LINE__); }
   }
+  chk(upload(&sc->spheres, spheres)); chk(upload(&sc->tris, tris));
   chk(upload(&sc->tri_verts, verts)); chk(upload(&sc->mats, mats));
   chk(upload(&sc->refs_in, refs)); chk(upload(&sc->planes, planes)); chk(upload(&sc->suns, suns)); chk(upload(&sc->bulbs, bulbs));
   auto alloc = [&](void** p, size_t bytes) { if (rc == MIRT_OK && bytes) { hipError_t e = hipMalloc(p, bytes); if (e != hipSuccess) rc = hip_fail(e, "hipMalloc", __FILE__, __LINE__); } };
   if (N > 0) {
     alloc((void**)&sc->codes, 4 * (size_t)N); alloc((void**)&sc->order, 4 * (size_t)N);
     alloc((void**)&sc->parent, 4 * (2 * (size_t)N - 1)); alloc((void**)&sc->boxes, 24 * (2 * (size_t)N - 1));
-    if (N > 1) { alloc((void**)&sc->child_l, 4 * (size_t)(N - 1)); alloc((void**)&sc->child_r, 4 * (size_t)(N - 1)); }
+    if (N > 1) { alloc((void**)&sc->child_l, 4 * (size_t)(N - 1)); alloc((void**)&sc->child_r, 4 * (size_t)(N - 1)); alloc((void**)&sc->range, 8 * (size_t)(N - 1)); }
+    alloc((void**)&sc->unit_prim, 4 * ((size_t)sc->Ns + 3 * (size_t)sc->Nt));
+    alloc((void**)&sc->tris_before, 4 * ((size_t)N + 1));
   }
   alloc((void**)&sc->bounds_keys, 6 * 4);
-  for (int i = 0; i < mirt::MIRT_MAX_FRAMES; ++i) alloc((void**)&sc->ctx[i].counters, 16 * sizeof(unsigned long long));
+  for (int i = 0; i < mirt::MIRT_MAX_FRAMES; ++i) {
+    alloc((void**)&sc->ctx[i].counters, 16 * sizeof(unsigned long long));
+    if (rc == MIRT_OK && hipMemset(sc->ctx[i].counters, 0, 16 * sizeof(unsigned long long)) != hipSuccess) rc = MIRT_ERR_HIP;
+  }
   if (rc == MIRT_OK) {
     hipError_t e = hipEventCreate(&sc->ev0);
     if (e == hipSuccess) e = hipEventCreate(&sc->ev1);
@@ -151,12 +223,17 @@ int mirt_scene_create(const MirtSceneDesc* d, int device, MirtScene** out)
   return MIRT_OK;
 }
 
+} // namespace
+
+extern "C" {
+
 void mirt_scene_destroy(MirtScene* sc)
 {
   if (!sc) return;
   hipSetDevice(sc->device);
   hipDeviceSynchronize();
-  hipFree(sc->heap); hipFree(sc->tri_verts); hipFree(sc->mats); hipFree(sc->refs_in);
+  hipFree(sc->heap); hipFree(sc->spheres); hipFree(sc->tris); hipFree(sc->tri_verts); hipFree(sc->mats); hipFree(sc->refs_in);
+  hipFree(sc->unit_prim); hipFree(sc->tris_before); hipFree(sc->range);
   hipFree(sc->planes); hipFree(sc->suns); hipFree(sc->bulbs);
   hipFree(sc->codes); hipFree(sc->order); hipFree(sc->child_l); hipFree(sc->child_r); hipFree(sc->parent); hipFree(sc->boxes); hipFree(sc->build_ws);
   hipFree(sc->bounds_keys);
@@ -212,6 +289,13 @@ int mirt_get_stats(MirtScene* sc, MirtStats* out)
   if (!sc->last) return MIRT_OK;
   for (int i = 0; i < mirt::MIRT_MAX_FRAMES; ++i) {   // finish and time every frame still in flight
     mirt::RenderCtx& c = sc->ctx[i];
+    if (c.used) {     // capacity overflows of the frames this context rendered since the previous call
+      MIRT_HIP(hipEventSynchronize(c.ev3));
+      unsigned long long ov = 0;
+      MIRT_HIP(hipMemcpy(&ov, c.counters + 9, sizeof(ov), hipMemcpyDeviceToHost));
+      sc->overflow_events += ov;
+      MIRT_HIP(hipMemset(c.counters + 9, 0, sizeof(ov)));
+    }
     if (c.used && !c.timed) {
       MIRT_HIP(hipEventSynchronize(c.ev3));
       float ms = 0.0f;
@@ -231,6 +315,12 @@ int mirt_get_stats(MirtScene* sc, MirtStats* out)
     MIRT_HIP(hipMemcpy(c, cx.counters, sizeof(c), hipMemcpyDeviceToHost));
     out->samples = c[0]; out->rays = c[1]; out->shadow_rays = c[2]; out->internal_visits = c[3];
     out->sphere_tests = c[4]; out->tri_tests = c[5]; out->mat_fetches = c[6]; out->max_stack = c[7];
+  }
+  out->overflow_events = sc->overflow_events;
+  sc->overflow_events = 0;
+  if (out->overflow_events) {
+    set_error("mirt_get_stats: capacity overflow during a render (traversal stack deeper than 64 entries or pending-ray list full): the image is missing contributions");
+    return MIRT_ERR_STATE;
   }
   return MIRT_OK;
 }

@@ -6,8 +6,11 @@
 //   morton_kernel        30-bit codes (lbvh_utils.cu:10-75)
 //   radix_pass_kernel    stable LSD radix sort, 4 passes x 8 bits, wave64 ballot ranking (replaces thrust::sort_by_key)
 //   karras_kernel        Karras 2012 hierarchy with the reference's index tie-break (lbvh_builder.cu:76-322)
+//   tri_scan_*           exclusive scan of the triangle flags in sorted order: where each sorted leaf's record goes in the
+//                        heap, and which subtrees hold spheres only
 //   refit_pack_kernel    bottom-up boxes (lbvh_builder.cu:324-387, with the missing release/acquire added) and
 //                        64-byte two-child node records for the traversal kernel
+//   scatter_prims_kernel primitive records into the heap in sorted order (neighbours in space are neighbours in memory)
 #include "scene_dev.h"
 #include "host_scene.h"
 
@@ -247,7 +250,7 @@ MIRT_DEV int delta(int a, int b, int n, const uint32_t* __restrict__ codes)
 // generate_internal_nodes_karas_kernel, lbvh_builder.cu:224-322 (+ determine_range_adapted :103-182,
 // find_split_adapted :186-221).  Children use the reference numbering: internal i in [0,N-2], leaf j -> N-1+j.
 __global__ void __launch_bounds__(BLOCK) karras_kernel(const uint32_t* __restrict__ codes, int n, uint32_t* __restrict__ child_l,
-                                                       uint32_t* __restrict__ child_r, int* __restrict__ parent)
+                                                       uint32_t* __restrict__ child_r, int* __restrict__ parent, uint2* __restrict__ range)
 {
   const int i = blockIdx.x * BLOCK + threadIdx.x;
   if (i >= n - 1) return;
@@ -273,6 +276,7 @@ __global__ void __launch_bounds__(BLOCK) karras_kernel(const uint32_t* __restric
   }
   const int j = (int)((uint32_t)i + l * (uint32_t)d);
   const int first = (i < j) ? i : j, last = (i < j) ? j : i;
+  range[i] = make_uint2((uint32_t)first, (uint32_t)last);
   // split
   int split = first;
   if (first != last) {
@@ -302,12 +306,103 @@ __global__ void __launch_bounds__(BLOCK) karras_kernel(const uint32_t* __restric
   if (i == 0) parent[0] = -1;
 }
 
-MIRT_DEV uint32_t make_ref(uint32_t node, uint32_t leaf_base, const uint32_t* __restrict__ order, const MirtPrimRef* __restrict__ refs,
-                           uint32_t sph_base16, uint32_t tri_base16)
+// ---- where the primitive records go: exclusive scan of the triangle flags over the sorted leaves ------------------------
+// Sorted leaf j's record starts at unit j + 2 * tris_before[j] of the primitive region (a sphere is one 16-byte unit, a
+// triangle three), and leaves [f, l] hold spheres only iff tris_before[l + 1] == tris_before[f].
+constexpr int SCAN_ITEMS = 8;
+constexpr int SCAN_TILE = BLOCK * SCAN_ITEMS;
+
+MIRT_DEV uint32_t block_exclusive_scan(uint32_t v, uint32_t* sh /* [BLOCK] */, uint32_t* total)
 {
-  if (node < leaf_base) return 4u * node;
-  const MirtPrimRef r = refs[order[node - leaf_base]];
-  return r.type ? (REF_LEAF | REF_TRI | (tri_base16 + 3u * r.id)) : (REF_LEAF | (sph_base16 + r.id));
+  const int tid = threadIdx.x;
+  sh[tid] = v;
+  __syncthreads();
+  for (int o = 1; o < BLOCK; o <<= 1) {
+    const uint32_t x = (tid >= o) ? sh[tid - o] : 0;
+    __syncthreads();
+    sh[tid] += x;
+    __syncthreads();
+  }
+  const uint32_t incl = sh[tid];
+  if (total) *total = sh[BLOCK - 1];
+  __syncthreads();
+  return incl - v;
+}
+
+template <bool WRITE>
+__global__ void __launch_bounds__(BLOCK) tri_scan_kernel(int n, const uint32_t* __restrict__ order, const MirtPrimRef* __restrict__ refs,
+                                                         uint32_t* __restrict__ block_sums, uint32_t* __restrict__ tris_before)
+{
+  __shared__ uint32_t sh[BLOCK];
+  const int base = blockIdx.x * SCAN_TILE + threadIdx.x * SCAN_ITEMS;
+  uint32_t f[SCAN_ITEMS], s = 0;
+#pragma unroll
+  for (int k = 0; k < SCAN_ITEMS; ++k) {
+    const int j = base + k;
+    f[k] = (j < n) ? (refs[order[j]].type != 0 ? 1u : 0u) : 0u;
+    s += f[k];
+  }
+  uint32_t total;
+  uint32_t run = block_exclusive_scan(s, sh, &total);
+  if (!WRITE) { if (threadIdx.x == 0) block_sums[blockIdx.x] = total; return; }
+  run += block_sums[blockIdx.x];                // exclusive prefix of the blocks before this one
+#pragma unroll
+  for (int k = 0; k < SCAN_ITEMS; ++k) {
+    const int j = base + k;
+    if (j < n) tris_before[j] = run;
+    run += f[k];
+    if (j == n - 1) tris_before[n] = run;
+  }
+}
+// one block: block_sums -> exclusive prefix, in place
+__global__ void __launch_bounds__(BLOCK) scan_sums_kernel(uint32_t* __restrict__ block_sums, int nb)
+{
+  __shared__ uint32_t sh[BLOCK];
+  uint32_t carry = 0;
+  for (int b0 = 0; b0 < nb; b0 += BLOCK) {
+    const int i = b0 + threadIdx.x;
+    const uint32_t v = (i < nb) ? block_sums[i] : 0u;
+    uint32_t total;
+    const uint32_t ex = block_exclusive_scan(v, sh, &total);
+    if (i < nb) block_sums[i] = carry + ex;
+    carry += total;
+  }
+}
+
+// reference to child `node` (reference numbering: internal [0, N-2], leaf j -> N-1+j) as the traversal kernels want it
+MIRT_DEV uint32_t make_ref(uint32_t node, uint32_t leaf_base, const uint32_t* __restrict__ order, const MirtPrimRef* __restrict__ refs,
+                           const uint32_t* __restrict__ tris_before, const uint2* __restrict__ range, uint32_t prim_base16, bool* pure)
+{
+  if (node >= leaf_base) {
+    const uint32_t j = node - leaf_base;
+    const bool tri = refs[order[j]].type != 0;
+    *pure = !tri;
+    return REF_LEAF | (tri ? REF_TRI : 0u) | (prim_base16 + j + 2u * tris_before[j]);
+  }
+  const uint2 fl = range[node];
+  *pure = tris_before[fl.y + 1] == tris_before[fl.x];
+  return 4u * node;
+}
+
+// primitive records in sorted order + the unit -> primitive map the shading code uses to find the material
+__global__ void __launch_bounds__(BLOCK) scatter_prims_kernel(int n, const uint32_t* __restrict__ order, const MirtPrimRef* __restrict__ refs,
+                                                              const uint32_t* __restrict__ tris_before, const float4* __restrict__ spheres,
+                                                              const float4* __restrict__ tris, float4* __restrict__ prim_region,
+                                                              uint32_t* __restrict__ unit_prim)
+{
+  const int j = blockIdx.x * BLOCK + threadIdx.x;
+  if (j >= n) return;
+  const MirtPrimRef r = refs[order[j]];
+  const size_t unit = (size_t)j + 2 * (size_t)tris_before[j];
+  if (r.type == 0) {
+    prim_region[unit] = spheres[r.id];
+    unit_prim[unit] = r.id;
+  } else {
+    prim_region[unit + 0] = tris[3 * (size_t)r.id + 0];
+    prim_region[unit + 1] = tris[3 * (size_t)r.id + 1];
+    prim_region[unit + 2] = tris[3 * (size_t)r.id + 2];
+    unit_prim[unit + 0] = 0x80000000u | r.id; unit_prim[unit + 1] = 0x80000000u | r.id; unit_prim[unit + 2] = 0x80000000u | r.id;
+  }
 }
 
 // set_aabb_kernel_adapted, lbvh_builder.cu:324-387.  One thread per leaf; the second thread to arrive at a parent
@@ -317,7 +412,8 @@ __global__ void __launch_bounds__(BLOCK) refit_pack_kernel(int n, const uint32_t
                                                            const float4* __restrict__ spheres, const float4* __restrict__ tri_verts,
                                                            const uint32_t* __restrict__ child_l, const uint32_t* __restrict__ child_r,
                                                            const int* __restrict__ parent, uint32_t* __restrict__ arrived,
-                                                           float* boxes, float4* __restrict__ nodes, uint32_t sph_base16, uint32_t tri_base16)
+                                                           float* boxes, float4* __restrict__ nodes, const uint32_t* __restrict__ tris_before,
+                                                           const uint2* __restrict__ range, uint32_t prim_base16)
 {
   const int j = blockIdx.x * BLOCK + threadIdx.x;
   if (j >= n) return;
@@ -352,8 +448,11 @@ __global__ void __launch_bounds__(BLOCK) refit_pack_kernel(int n, const uint32_t
     rec[0] = make_float4(a0, a1, a2, a3);
     rec[1] = make_float4(a4, a5, c0, c1);
     rec[2] = make_float4(c2, c3, c4, c5);
-    rec[3] = make_float4(__uint_as_float(make_ref(lc, leaf_base, order, refs, sph_base16, tri_base16)),
-                         __uint_as_float(make_ref(rc, leaf_base, order, refs, sph_base16, tri_base16)), 0.0f, 0.0f);
+    bool pure_l, pure_r;
+    const uint32_t ref_l = make_ref(lc, leaf_base, order, refs, tris_before, range, prim_base16, &pure_l);
+    const uint32_t ref_r = make_ref(rc, leaf_base, order, refs, tris_before, range, prim_base16, &pure_r);
+    rec[3] = make_float4(__uint_as_float(ref_l), __uint_as_float(ref_r),
+                         __uint_as_float(NODE_SWAP_ANY | ((pure_l && pure_r) ? NODE_SWAP_PURE : 0u)), 0.0f);
     // AABB(AABB, AABB), interval.cuh:83-88
     float* pb = boxes + 6 * (size_t)p;
     __hip_atomic_store(pb + 0, fminf(a0, c0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); __hip_atomic_store(pb + 1, fmaxf(a1, c1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -383,11 +482,17 @@ int build_lbvh(MirtScene* sc, hipStream_t stream)
   }
   MIRT_HIP(hipEventRecord(sc->ev0, stream));
   // scene bounds
-  static const uint32_t init_keys[6] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0u, 0u, 0u};
-  MIRT_HIP(hipMemcpyAsync(sc->bounds_keys, init_keys, sizeof(init_keys), hipMemcpyHostToDevice, stream));
   const int nblk = (n + BLOCK - 1) / BLOCK;
-  const int bgrid = nblk < 512 ? nblk : 512;
-  hipLaunchKernelGGL(prim_bounds_kernel, dim3(bgrid), dim3(BLOCK), 0, stream, sc->refs_in, sc->spheres, sc->tri_verts, n, sc->bounds_keys);
+  if (!sc->opt.bounds_as_shipped) {
+    static const uint32_t init_keys[6] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0u, 0u, 0u};
+    MIRT_HIP(hipMemcpyAsync(sc->bounds_keys, init_keys, sizeof(init_keys), hipMemcpyHostToDevice, stream));
+    const int bgrid = nblk < 512 ? nblk : 512;
+    hipLaunchKernelGGL(prim_bounds_kernel, dim3(bgrid), dim3(BLOCK), 0, stream, sc->refs_in, sc->spheres, sc->tri_verts, n, sc->bounds_keys);
+  } else {
+    // the shipped reference never stores the bounds it accumulates (parse.cpp:28): min = +inf, max = -inf, every code 0
+    static const uint32_t shipped_keys[6] = {0xff800000u, 0xff800000u, 0xff800000u, 0x007fffffu, 0x007fffffu, 0x007fffffu};
+    MIRT_HIP(hipMemcpyAsync(sc->bounds_keys, shipped_keys, sizeof(shipped_keys), hipMemcpyHostToDevice, stream));
+  }
 
   // morton codes + stable sort
   uint32_t* const ws = sc->build_ws;
@@ -411,26 +516,27 @@ int build_lbvh(MirtScene* sc, hipStream_t stream)
     MIRT_HIP(hipMemsetAsync(arrived, 0, sizeof(uint32_t) * (n - 1), stream));
     MIRT_HIP(hipMemsetAsync(sc->parent, 0xff, sizeof(int) * (2 * (size_t)n - 1), stream));
     const int kblk = (n - 1 + BLOCK - 1) / BLOCK;
-    hipLaunchKernelGGL(karras_kernel, dim3(kblk), dim3(BLOCK), 0, stream, sc->codes, n, sc->child_l, sc->child_r, sc->parent);
+    hipLaunchKernelGGL(karras_kernel, dim3(kblk), dim3(BLOCK), 0, stream, sc->codes, n, sc->child_l, sc->child_r, sc->parent, sc->range);
   } else {
     MIRT_HIP(hipMemsetAsync(sc->parent, 0xff, sizeof(int), stream));
   }
+  // heap placement of the sorted leaves (the sort workspace is free again: the block sums live in it)
+  const int scan_blocks = (n + SCAN_TILE - 1) / SCAN_TILE;
+  uint32_t* const block_sums = k1;
+  hipLaunchKernelGGL(tri_scan_kernel<false>, dim3(scan_blocks), dim3(BLOCK), 0, stream, n, sc->order, sc->refs_in, block_sums, sc->tris_before);
+  hipLaunchKernelGGL(scan_sums_kernel, dim3(1), dim3(BLOCK), 0, stream, block_sums, scan_blocks);
+  hipLaunchKernelGGL(tri_scan_kernel<true>, dim3(scan_blocks), dim3(BLOCK), 0, stream, n, sc->order, sc->refs_in, block_sums, sc->tris_before);
+  hipLaunchKernelGGL(scatter_prims_kernel, dim3(nblk), dim3(BLOCK), 0, stream, n, sc->order, sc->refs_in, sc->tris_before, sc->spheres, sc->tris,
+                     reinterpret_cast<float4*>(sc->heap + sc->prim_base), sc->unit_prim);
   hipLaunchKernelGGL(refit_pack_kernel, dim3(nblk), dim3(BLOCK), 0, stream, n, sc->order, sc->refs_in, sc->spheres, sc->tri_verts,
-                     sc->child_l, sc->child_r, sc->parent, arrived, sc->boxes, sc->nodes, sc->sph_base / 16u, sc->tri_base / 16u);
+                     sc->child_l, sc->child_r, sc->parent, arrived, sc->boxes, sc->nodes, sc->tris_before, sc->range, sc->prim_base / 16u);
   MIRT_HIP(hipGetLastError());
   MIRT_HIP(hipEventRecord(sc->ev1, stream));
   MIRT_HIP(hipStreamSynchronize(stream));   // lbvh_builder.cu:475
   MIRT_HIP(hipEventElapsedTime(&sc->build_ms, sc->ev0, sc->ev1));
 
-  if (n == 1) {
-    uint32_t ord = 0;
-    MIRT_HIP(hipMemcpy(&ord, sc->order, 4, hipMemcpyDeviceToHost));
-    MirtPrimRef r;
-    MIRT_HIP(hipMemcpy(&r, sc->refs_in + ord, sizeof(r), hipMemcpyDeviceToHost));
-    sc->root_ref = r.type ? (REF_LEAF | REF_TRI | (sc->tri_base / 16u + 3u * r.id)) : (REF_LEAF | (sc->sph_base / 16u + r.id));
-  } else {
-    sc->root_ref = 0;
-  }
+  // root: node 0, unless the whole scene is a single primitive
+  sc->root_ref = (n == 1) ? (REF_LEAF | (sc->Nt ? REF_TRI : 0u) | (sc->prim_base / 16u)) : 0u;
   sc->built = true;
   return MIRT_OK;
 }

@@ -32,6 +32,7 @@ namespace mirt {
 namespace {
 
 constexpr int RBLOCK = 256;
+constexpr int MAX_SPP = 4096;         // resolve_kernel's partial-sum stack holds log2(4096) + 1 entries
 // The trace kernel's waves never talk to each other, so a workgroup is one wave: a finished wave frees its slot (and its
 // 10 KB of LDS) at once instead of waiting for the slowest of four, which is what lets the next frame's waves move in
 // while this frame drains.
@@ -40,7 +41,6 @@ constexpr int RBLOCK = 256;
 #endif
 constexpr int TRACE_BLOCK = MIRT_TRACE_BLOCK;
 constexpr int MAX_CHUNK_SHIFT = 8, MIN_CHUNK_SHIFT = 6;   // a wave takes 64..256 consecutive samples from the frame per atomic
-constexpr int DRAIN_LANES = 16;       // a wave with this few live lanes (and no work left to fetch) stops batching
 #ifndef MIRT_DEFAULT_WAVEFRONT
 #define MIRT_DEFAULT_WAVEFRONT 0
 #endif
@@ -207,36 +207,15 @@ __global__ void __launch_bounds__(TRACE_BLOCK, MIRT_WAVES_PER_SIMD) trace_kernel
           bool hit = false;
           const float4 q0 = rec[0];
           if (S.cur & REF_TRI) {
-            // checkTriangleIntersectionSoA, struct.cu:111-163.  The early returns of the reference become one boolean:
-            // a wave with several lanes here never skips the code anyway, and values computed past a failed test
-            // (a division by ~0, a barycentric of a point behind the ray) are simply not selected.
             if (COUNT) cn.tri_tests++;
             const float4 q1 = rec[1], q2 = rec[2];
-            const f3 p0 = mk3(q0.x, q0.y, q0.z), nor = mk3(q0.w, q1.x, q1.y);
-            const float denom = dot(S.d, nor);
-            t = dot(p0 - S.o, nor) / denom;
-            const f3 ip = t * S.d + S.o;
-            const f3 e1 = mk3(q1.z, q1.w, q2.x), e2 = mk3(q2.y, q2.z, q2.w);
-            const float b1 = dot(e1, ip - p0);
-            const float b2 = dot(e2, ip - p0);
-            const float b0 = 1.0f - b1 - b2;
-            hit = !(fabsf(denom) < 1e-9f) && !(t <= EPSILON) && (b0 >= -EPSILON) && (b1 >= -EPSILON) && (b2 >= -EPSILON);
+            hit = triangle_hit(q0, q1, q2, S.o, S.d, t);
           } else {
-            // checkSphereIntersectionSoA, struct.cu:64-109 (same remark)
             if (COUNT) cn.sphere_tests++;
-            const f3 c = mk3(q0.x, q0.y, q0.z);
-            const float r = q0.w;
-            const f3 cr0 = c - S.o;
-            const bool inside = (dot(cr0, cr0) < r * r);
-            const float tc = dot(cr0, S.d);
-            const f3 dv = S.o + (tc * S.d) - c;
-            const float d2 = dot(dv, dv);
-            const float toff = sqrtf((r * r) - d2);
-            t = inside ? (tc + toff) : (tc - toff);
-            hit = !(!inside && tc < 0.0f) && !(!inside && (r * r) < d2);
+            hit = sphere_hit(q0, S.o, S.d, t);
           }
           // (S.trav is true here)
-          const bool closer = hit && t > 1e-6f && t < S.tbest;
+          const bool closer = closer_hit(hit, t, S.tbest, S.cur & REF_OFFMASK, S.refbest);
           S.tbest = closer ? t : S.tbest;
           S.refbest = closer ? S.cur : S.refbest;
           S.trav = !(closer && S.shadow && t < S.limit);      // any-hit exit
@@ -250,11 +229,14 @@ __global__ void __launch_bounds__(TRACE_BLOCK, MIRT_WAVES_PER_SIMD) trace_kernel
           asm volatile("" : "+v"(noff));
           const float4* nrec = reinterpret_cast<const float4*>(heap + noff);
           const float4 q0 = nrec[0], q1 = nrec[1], q2 = nrec[2];
-          const uint2 ch = *reinterpret_cast<const uint2*>(nrec + 3);
+          const uint4 ch = *reinterpret_cast<const uint4*>(nrec + 3);      // child references, NODE_SWAP_* flags
           bool hl, hr;
-          box_pair(q0, q1, q2, S.o.x, S.o.y, S.o.z, S.inv.x, S.inv.y, S.inv.z, S.tbest, tmin, hl, hr);
-          const uint32_t lref = ch.x, rref = ch.y;
-          // left first, push right (bvh_traversal.cu:149-157), written with selects: one short branch for the push
+          float tel, ter;
+          box_pair(q0, q1, q2, S.o.x, S.o.y, S.o.z, S.inv.x, S.inv.y, S.inv.z, S.tbest, tmin, hl, hr, tel, ter);
+          uint32_t lref = ch.x, rref = ch.y;
+          order_children(hl, hr, tel, ter, ch.z, h.swap_mask, lref, rref);
+          // first child next, push the second (bvh_traversal.cu:149-157: left, right), written with selects: one short
+          // branch for the push
           const bool both = hl && hr;
           if (both && S.sp < STACK_TOTAL) {
             // the previous top of stack goes to memory, the new top stays in a register.  With n entries on the stack,
@@ -266,6 +248,9 @@ __global__ void __launch_bounds__(TRACE_BLOCK, MIRT_WAVES_PER_SIMD) trace_kernel
             ++S.sp;
             if (COUNT) cn.max_stack = max(cn.max_stack, (uint32_t)S.sp);
           }
+          // a stack beyond the reference's 64 entries: the reference warns and drops the subtree (:154-164); here the sample
+          // is marked (top bit of its step count) and reported as an error when it completes -- no atomic in this loop
+          S.steps |= (both && S.sp >= STACK_TOTAL) ? 0x80000000u : 0u;
           S.cur = hl ? lref : (hr ? rref : S.cur);
           pop = !(hl || hr);
         }
@@ -365,7 +350,7 @@ __global__ void __launch_bounds__(RBLOCK) resolve_kernel(const ResolveArgs a)
     int P = 1, lg = 0;
     while (P < a.spp) { P <<= 1; ++lg; }
     const float4* s = a.samples + lp * a.spp;
-    float4 stk[12];
+    float4 stk[13];
     int top = 0;
     for (int i = 0; i < P; ++i) {
       const int idx = (int)(__brev((unsigned)i) >> (32 - lg));
@@ -556,6 +541,7 @@ int render(MirtScene* sc, const MirtRenderParams* p, void* d_rgba8, void* d_rgba
   if (!sc->built) { set_error("mirt_render: call mirt_build_lbvh first"); return MIRT_ERR_STATE; }
   const int64_t npix = local_pixels(p);
   if (npix < 0 || p->spp < 0 || !d_rgba8) { set_error("mirt_render: bad parameters"); return MIRT_ERR_ARG; }
+  if (p->spp > MAX_SPP) { set_error("mirt_render: more than 4096 samples per pixel in one call"); return MIRT_ERR_ARG; }
   if ((int64_t)p->width * p->height > 0x7fffffffll - 1234) { set_error("mirt_render: frame too large for the 32-bit pixel seed"); return MIRT_ERR_ARG; }
   if (npix == 0) return MIRT_OK;
   if ((long long)npix * (p->spp > 1 ? p->spp : 1) >= 0xffffffffll || (long long)p->stripe_rows * p->width >= 0x7fffffffll) {
@@ -565,8 +551,9 @@ int render(MirtScene* sc, const MirtRenderParams* p, void* d_rgba8, void* d_rgba
   const long long nsamples = (long long)npix * sppe;
   const bool count = (p->flags & MIRT_RENDER_COUNTERS) != 0;
 
-  static int blocks_cached = 0;
-  if (!blocks_cached) blocks_cached = grid_blocks(sc->device);
+  const Options& opt = sc->opt;
+  if (!sc->grid_blocks) sc->grid_blocks = grid_blocks(sc->device);      // per scene, i.e. per device
+  const int blocks_cached = sc->grid_blocks;
   long long want_blocks = (nsamples + TRACE_BLOCK - 1) / TRACE_BLOCK;
   int blocks = (int)(want_blocks < blocks_cached ? want_blocks : blocks_cached);
   // A small frame (one GPU's stripe set of an 8-GPU job) rendered while another frame is in flight gets half the grid:
@@ -576,15 +563,15 @@ int render(MirtScene* sc, const MirtRenderParams* p, void* d_rgba8, void* d_rgba
   if (!count && blocks == blocks_cached && nsamples < 20ll * blocks_cached * TRACE_BLOCK) {
     for (int i = 0; i < MIRT_MAX_FRAMES; ++i) {
       const RenderCtx& c = sc->ctx[i];
-      if (c.used && c.stream != stream && hipEventQuery(c.ev3) == hipErrorNotReady) { blocks = blocks_cached / 2; break; }   // (a frame on this same stream does not overlap)
+      if (c.used && c.stream != stream && hipEventQuery(c.ev3) == hipErrorNotReady) { blocks = blocks_cached > 1 ? blocks_cached / 2 : 1; break; }   // (a frame on this same stream does not overlap)
     }
   }
-  if (const char* e = getenv("MIRT_TRACE_WAVES")) { const int k = atoi(e); if (k >= 1 && k <= blocks_cached) blocks = k; }   // experiments
+  if (opt.trace_waves >= 1 && opt.trace_waves <= blocks_cached) blocks = opt.trace_waves;
   const size_t gthreads = (size_t)blocks * TRACE_BLOCK;
 
-  // this frame's context; wait for the frame that used it MIRT_MAX_FRAMES renders ago
+  // this frame's context; wait for the frame that used it MIRT_MAX_FRAMES renders ago (the frame counter moves only once
+  // the frame is actually issued, below)
   RenderCtx& cx = sc->ctx[sc->frame_no % MIRT_MAX_FRAMES];
-  ++sc->frame_no;
   if (cx.used) {
     MIRT_HIP(hipEventSynchronize(cx.ev3));
     if (!cx.timed) {   // fold the finished frame's trace-kernel time into the running mean (mirt_get_stats)
@@ -628,9 +615,10 @@ int render(MirtScene* sc, const MirtRenderParams* p, void* d_rgba8, void* d_rgba
   a.eye.x = sc->d.eye.x; a.eye.y = sc->d.eye.y; a.eye.z = sc->d.eye.z;
   a.stripe_rows = p->stripe_rows; a.num_parts = p->num_parts; a.part = p->part;
   a.num_local_pixels = npix; a.num_samples = nsamples;
-  a.nodes = sc->nodes; a.spheres = sc->spheres; a.tris = sc->tris; a.mats = sc->mats;
+  a.nodes = sc->nodes; a.unit_prim = sc->unit_prim; a.mats = sc->mats;
   a.root_ref = sc->root_ref; a.num_spheres = sc->Ns; a.num_prims = sc->N;
-  a.sph_base = sc->sph_base; a.tri_base = sc->tri_base;
+  a.prim_base16 = sc->prim_base / 16u;
+  a.swap_mask = opt.traversal == 1 ? NODE_SWAP_PURE : (opt.traversal == 2 ? NODE_SWAP_ANY : 0u);
   a.planes = sc->planes; a.num_planes = sc->d.num_planes;
   a.suns = sc->suns; a.num_suns = sc->d.num_suns;
   a.bulbs = sc->bulbs; a.num_bulbs = sc->d.num_bulbs;
@@ -644,21 +632,18 @@ int render(MirtScene* sc, const MirtRenderParams* p, void* d_rgba8, void* d_rgba
   a.stack_spill = cx.stack_spill;
   a.pending = cx.pending; a.pending_slots = pending_slots;
   a.counters = count ? cx.counters : nullptr;
-  a.lds_depth = STACK_LDS;
-  if (const char* e = getenv("MIRT_STACK_LDS_DEPTH")) { int k = atoi(e); if (k >= 0 && k <= STACK_LDS) a.lds_depth = k; }   // tests: force the spill path
-  a.refill_k = 44;     // measured with four steps per header pass: 32..48 within 1 %, 44 best on all three bundled scenes
-  a.drain_lanes = DRAIN_LANES;
-  if (const char* e = getenv("MIRT_DRAIN_LANES")) { int k = atoi(e); if (k >= 0 && k <= 64) a.drain_lanes = k; }
-  a.batch_k = 8;
-  if (const char* e = getenv("MIRT_BATCH_K")) { int k = atoi(e); if (k >= 1 && k <= 64) a.batch_k = k; }
-  if (const char* e = getenv("MIRT_REFILL_K")) { int k = atoi(e); if (k >= 1 && k <= 64) a.refill_k = k; }
+  a.overflow = cx.counters + 9;
+  a.lds_depth = (opt.stack_lds_depth >= 0 && opt.stack_lds_depth <= STACK_LDS) ? opt.stack_lds_depth : STACK_LDS;   // tests force the spill path
+  a.refill_k = opt.refill_k;
+  a.drain_lanes = opt.drain_lanes;
+  a.batch_k = opt.batch_k;
 
   // ---- longest-first chunk order (single-kernel path) ----------------------------------------------------------------
   // chunk size: 256 samples, smaller for a small (part of a) frame so that every wave still gets a dozen chunks or more --
   // with four chunks per wave (1/8 of a 1080p frame) the waves finished up to a chunk apart
   int chunk_shift = MAX_CHUNK_SHIFT;
   while (chunk_shift > MIN_CHUNK_SHIFT && (nsamples >> chunk_shift) < 16ll * blocks * (TRACE_BLOCK / 64)) --chunk_shift;
-  if (const char* e = getenv("MIRT_CHUNK_SHIFT")) { const int k = atoi(e); if (k >= 4 && k <= 12) chunk_shift = k; }
+  if (opt.chunk_shift >= 4) chunk_shift = opt.chunk_shift;
   a.chunk_shift = chunk_shift;
   const size_t nchunks = (size_t)((nsamples + (1ll << chunk_shift) - 1) >> chunk_shift);
   if (cx.chunk_cap < nchunks) {
@@ -682,7 +667,7 @@ int render(MirtScene* sc, const MirtRenderParams* p, void* d_rgba8, void* d_rgba
     }
     if (!order && cx.used && cx.order_key == okey) order = cx.order_out[(cx.uses - 1) % RenderCtx::ORDER_BUFS];   // cx's own previous frame (finished: synchronised above)
   }
-  static const bool sched = getenv("MIRT_NO_SCHED") == nullptr;
+  const bool sched = opt.sched != 0;
   if (!sched) order = nullptr;
   a.chunk_order = order;
   a.chunk_cost = sched ? cx.chunk_cost : nullptr;
@@ -690,28 +675,29 @@ int render(MirtScene* sc, const MirtRenderParams* p, void* d_rgba8, void* d_rgba
   MIRT_HIP(hipEventRecord(cx.ev0, stream));
   if (sched) MIRT_HIP(hipMemsetAsync(cx.chunk_cost, 0, 4 * nchunks, stream));
   if (count) MIRT_HIP(hipMemsetAsync(cx.counters, 0, 8 * sizeof(unsigned long long), stream));
-  MIRT_HIP(hipMemsetAsync(cx.counters + 8, 0, sizeof(unsigned long long), stream));
+  MIRT_HIP(hipMemsetAsync(cx.counters + 8, 0, sizeof(unsigned long long), stream));     // work counter ([9], the overflow events, is only reset by mirt_get_stats)
   a.work_counter = cx.counters + 8;
   MIRT_HIP(hipEventRecord(cx.ev1, stream));
-  const bool prof = getenv("MIRT_PROF") != nullptr;
-  const char* wfe = getenv("MIRT_WAVEFRONT");
-  const bool wavefront = wfe ? atoi(wfe) != 0 : MIRT_DEFAULT_WAVEFRONT;
+#if MIRT_DIAG_PROF
+  const bool prof = getenv("MIRT_PROF") != nullptr;      // diagnostic build only (tools/ab.py NAME -DMIRT_DIAG_PROF=1)
+#else
+  const bool prof = false;
+#endif
+  const bool wavefront = opt.wavefront != 0;
   cx.wf_trace_ms = -1.0f;
   if (wavefront) {
-    if (const char* e = getenv("MIRT_WF_REFILL_K")) { int k = atoi(e); if (k >= 1 && k <= 64) a.refill_k = k; } else a.refill_k = 16;
+    a.refill_k = opt.wf_refill_k;
     float tms = 0.0f;
     int rc = wavefront_trace(sc, cx, a, count, stream, &tms);
     if (rc != MIRT_OK) return rc;
     cx.wf_trace_ms = tms;
   } else {
     HotArgs h;
-    h.nodes = a.nodes; h.root_ref = a.root_ref;
+    h.nodes = a.nodes; h.root_ref = a.root_ref; h.swap_mask = a.swap_mask;
     h.planes = a.planes; h.num_planes = a.num_planes; h.suns = a.suns; h.num_suns = a.num_suns; h.bulbs = a.bulbs; h.num_bulbs = a.num_bulbs;
     h.stack_spill = a.stack_spill; h.lds_depth = a.lds_depth; h.refill_k = a.refill_k; h.batch_k = a.batch_k; h.drain_lanes = a.drain_lanes;
-    h.leaf_k = 8;
-    h.reps = 4;
-    if (const char* e = getenv("MIRT_REPS")) { int k = atoi(e); if (k >= 1 && k <= 8) h.reps = k; }
-    if (const char* e = getenv("MIRT_LEAF_K")) { int k = atoi(e); if (k >= 1 && k <= 64) h.leaf_k = k; }
+    h.leaf_k = opt.leaf_k;
+    h.reps = opt.reps;
     h.prof = nullptr;
     if (!cx.args_dev) MIRT_HIP(hipMalloc(&cx.args_dev, sizeof(RenderArgs)));
     if (prof) {
@@ -722,6 +708,7 @@ int render(MirtScene* sc, const MirtRenderParams* p, void* d_rgba8, void* d_rgba
       a.prof = cx.prof; h.prof = cx.prof;
     }
     MIRT_HIP(hipMemcpyAsync(cx.args_dev, &a, sizeof(RenderArgs), hipMemcpyHostToDevice, stream));
+#if MIRT_DIAG_PROF
     if (prof) {
       hipLaunchKernelGGL((trace_kernel<false, true>), dim3(blocks), dim3(TRACE_BLOCK), 0, stream, cx.args_dev, h);
       MIRT_HIP(hipStreamSynchronize(stream));
@@ -752,7 +739,9 @@ int render(MirtScene* sc, const MirtRenderParams* p, void* d_rgba8, void* d_rgba
         fprintf(stderr, "[mirt prof] per-wave times, ms (min/10%%/50%%/90%%/max): start %.2f/%.2f/%.2f/%.2f/%.2f | queue empty %.2f/%.2f/%.2f/%.2f/%.2f | exit %.2f/%.2f/%.2f/%.2f/%.2f\n",
                 q(st, 0), q(st, .1), q(st, .5), q(st, .9), q(st, 1), q(ex, 0), q(ex, .1), q(ex, .5), q(ex, .9), q(ex, 1), q(en, 0), q(en, .1), q(en, .5), q(en, .9), q(en, 1));
       }
-    } else if (count) hipLaunchKernelGGL((trace_kernel<true, false>), dim3(blocks), dim3(TRACE_BLOCK), 0, stream, cx.args_dev, h);
+    } else
+#endif
+    if (count) hipLaunchKernelGGL((trace_kernel<true, false>), dim3(blocks), dim3(TRACE_BLOCK), 0, stream, cx.args_dev, h);
     else hipLaunchKernelGGL((trace_kernel<false, false>), dim3(blocks), dim3(TRACE_BLOCK), 0, stream, cx.args_dev, h);
   }
   MIRT_HIP(hipGetLastError());
@@ -779,6 +768,7 @@ int render(MirtScene* sc, const MirtRenderParams* p, void* d_rgba8, void* d_rgba
     cx.order_key = okey;
   } else cx.order_key = -1;
   ++cx.uses;
+  ++sc->frame_no;
   MIRT_HIP(hipEventRecord(cx.ev3, stream));
   cx.used = true; cx.counted = count; cx.timed = false; cx.stream = stream; sc->last = &cx;
   return MIRT_OK;

@@ -12,14 +12,19 @@
 
 namespace mirt {
 
-// child reference inside a packed node / the root reference: names a record of the heap [nodes | spheres | triangles]
+// child reference inside a packed node / the root reference: names a record of the heap [nodes | primitives]
 //   bit 31 = leaf (a primitive record); bit 30 = primitive type (0 sphere, 1 triangle);
-//   bits 0..27 = the record's offset in the heap in 16-byte units (node i: 4 i; sphere k: sph_base/16 + k; triangle k:
-//   tri_base/16 + 3 k), so that the traversal step gets a record's byte offset with one shift
+//   bits 0..27 = the record's offset in the heap in 16-byte units (node i: 4 i; the primitive of sorted leaf j:
+//   prim_base/16 + j + 2 * (triangles among leaves [0, j))), so that the traversal step gets a record's byte offset with
+//   one shift.  Primitive records are stored in sorted (Morton) order: the offset of a leaf grows with its sorted index,
+//   which is what breaks exact ties in the hit distance the way the reference's left-first walk does.
 constexpr uint32_t REF_LEAF = 0x80000000u;
 constexpr uint32_t REF_TRI = 0x40000000u;
 constexpr uint32_t REF_OFFMASK = 0x0fffffffu;  // the record's offset in the heap, in 16-byte units: `ref << 4` is its byte offset (the shift drops the flags)
-constexpr uint32_t REF_NONE = 0xffffffffu;   // empty scene / plane marker is separate
+constexpr uint32_t REF_NONE = 0xf0000000u;   // no record (bits 29..28 are set in no real reference; offset bits 0)
+// node record word 14 (after the two child references): which descent orders the node allows
+constexpr uint32_t NODE_SWAP_PURE = 1u;       // both subtrees hold spheres only: near-child-first cannot change the closest hit
+constexpr uint32_t NODE_SWAP_ANY = 2u;        // always set (the mask of MIRT_TRAVERSAL_ORDERED_ALL)
 
 struct PlaneDev { float nx, ny, nz, px, py, pz; float mat[11]; float pad; };   // 72 B
 // suns: direction; bulbs: position.  n* = normalize(direction) and i* = 1 / n* for suns, computed on the host with the same
@@ -38,12 +43,13 @@ struct RenderArgs {
   long long num_local_pixels;
   long long num_samples;          // num_local_pixels * max(spp,1)
   // geometry
-  const float4* nodes;            // 4 x float4 per internal node
-  const float4* spheres;          // (cx,cy,cz,r)
-  const float4* tris;             // 3 x float4: p0.xyz nor.x | nor.yz e1.xy | e1.z e2.xyz
+  const float4* nodes;            // record heap: 4 x float4 per internal node, then the primitive records in sorted order:
+                                  // sphere (cx,cy,cz,r); triangle 3 x float4: p0.xyz nor.x | nor.yz e1.xy | e1.z e2.xyz
+  const uint32_t* unit_prim;      // per 16-byte unit of the primitive region: type << 31 | index in the scene's sphere / triangle array
   const float4* mats;             // 3 x float4 per primitive: spheres first, then triangles
   uint32_t root_ref;
-  uint32_t sph_base, tri_base;    // byte offsets of the sphere / triangle arrays in the record heap that starts at `nodes`
+  uint32_t prim_base16;           // offset of the primitive region in the heap, in 16-byte units
+  uint32_t swap_mask;             // NODE_SWAP_* bits that allow near-child-first descent (0: the reference's left-first order)
   int num_spheres;
   int num_prims;
   const PlaneDev* planes; int num_planes;
@@ -62,6 +68,7 @@ struct RenderArgs {
   int drain_lanes;                // a wave with at most this many live lanes and nothing left to fetch stops batching
   int batch_k;                    // start the next rays of ray batches when this many lanes wait for one
   unsigned long long* counters;   // MirtStats head (8 x u64) or null
+  unsigned long long* overflow;   // never null: capacity overflows (traversal stack beyond 64, pending list), must stay 0
   unsigned long long* prof;       // diagnostic build only (MIRT_PROF)
   unsigned long long* work_counter; // next unclaimed chunk of the frame (single-kernel path)
   const uint32_t* chunk_order;      // chunk k of the hand-out order is chunk chunk_order[k] of the frame (null: identity)
@@ -75,6 +82,7 @@ struct RenderArgs {
 struct HotArgs {
   const float4* nodes;            // start of the record heap
   uint32_t root_ref;
+  uint32_t swap_mask;
   const PlaneDev* planes; int num_planes;
   const LightDev* suns; int num_suns;
   const LightDev* bulbs; int num_bulbs;
@@ -98,6 +106,22 @@ struct RngCache {
   RngTables host;
   long long key = -1;
   uint4* A = nullptr; uint32_t* B = nullptr; uint32_t* K = nullptr; uint32_t* R2 = nullptr;
+};
+
+// Mode switches and tuning values of a scene.  The defaults are the measured optima.  MIRT_<NAME> environment variables
+// override them ONCE, when the scene is created (tools/ sweeps); mirt_scene_set_option changes them afterwards.  Nothing
+// reads the environment during a render.
+struct Options {
+  int bounds_as_shipped = 0;   // build: 1 = scene bounds never stored, every Morton code 0 -- the tree of the shipped reference (parse.cpp:28)
+  int traversal = 1;           // MIRT_TRAVERSAL_*: 0 reference (left first), 1 ordered where pixels cannot change, 2 ordered everywhere
+  int wavefront = 0;           // 1: the trace / shade kernel pair instead of the single kernel
+  int stack_lds_depth = -1;    // traversal-stack entries kept in LDS (-1: the compiled size); tests force the spill path with it
+  int refill_k = 44;           // leave the traversal loop when this many lanes wait to shade (32..48 within 1 %)
+  int batch_k = 8, leaf_k = 8, reps = 4, drain_lanes = 16;
+  int chunk_shift = 0;         // 0: by frame size
+  int trace_waves = 0;         // 0: fill the device
+  int sched = 1;               // longest-first chunk order measured on earlier frames
+  int wf_pool = 1 << 21, wf_refill_k = 16;
 };
 
 constexpr int MIRT_MAX_FRAMES = 4;
@@ -133,9 +157,11 @@ struct MirtScene {
   int device = 0;
   MirtSceneDesc d{};
   int N = 0, Ns = 0, Nt = 0;
-  // uploaded geometry
-  float4* spheres = nullptr;
-  float4* tris = nullptr;
+  mirt::Options opt;
+  int grid_blocks = 0, wf_trace_blocks = 0;   // persistent-grid sizes for this scene's device (filled on first use)
+  // uploaded geometry, file order (inputs of the build)
+  float4* spheres = nullptr;            // (cx, cy, cz, r)
+  float4* tris = nullptr;               // 3 x float4 per triangle: p0.xyz nor.x | nor.yz e1.xy | e1.z e2.xyz
   float4* mats = nullptr;
   MirtPrimRef* refs_in = nullptr;       // file order
   float4* tri_verts = nullptr;          // 3 x float4 per triangle (p0,p1,p2) -- build only
@@ -149,9 +175,12 @@ struct MirtScene {
   uint32_t* child_r = nullptr;
   int* parent = nullptr;                // [2N-1]
   float* boxes = nullptr;               // [2N-1][6] xmin,xmax,ymin,ymax,zmin,zmax
-  float4* nodes = nullptr;              // packed [N-1][4]; start of the record heap [nodes | spheres | tris | pad]
+  float4* nodes = nullptr;              // packed [N-1][4]; start of the record heap [nodes | primitive records, sorted order | pad]
   unsigned char* heap = nullptr;
-  uint32_t sph_base = 0, tri_base = 0;
+  uint32_t prim_base = 0;               // byte offset of the primitive region in the heap
+  uint32_t* unit_prim = nullptr;        // [Ns + 3 Nt]: per 16-byte unit of the primitive region, type << 31 | index (first unit of a record)
+  uint32_t* tris_before = nullptr;      // [N + 1]: triangles among sorted leaves [0, j)
+  uint2* range = nullptr;               // [N - 1]: sorted-leaf range (first, last) of every internal node
   uint32_t* build_ws = nullptr; size_t build_ws_words = 0;   // LBVH build workspace (sort buffers, histograms, arrival counters)
   uint32_t* bounds_keys = nullptr;      // [6] ordered-uint min xyz, max xyz
   uint32_t root_ref = mirt::REF_NONE;
@@ -163,6 +192,7 @@ struct MirtScene {
   unsigned frame_no = 0;
   unsigned long long frame_seq = 0;
   mirt::RenderCtx* last = nullptr;        // context of the most recent render (mirt_get_stats)
+  unsigned long long overflow_events = 0;  // capacity overflows seen since the last mirt_get_stats
   double trace_ms_sum = 0.0; int trace_frames = 0;   // trace-kernel time of the frames finished since the last mirt_get_stats
   // wavefront path workspace (wavefront.hip)
   uint32_t* wf_state = nullptr; size_t wf_state_cap = 0;

@@ -110,7 +110,7 @@ MIRT_DEV f3 rough_normal(const f3& n, float roughness, Xorwow& rng)
 // lane value is the same single-rounded (plane - origin) * inv_dir product as in the scalar form.
 typedef float v2f __attribute__((ext_vector_type(2)));
 MIRT_DEV void box_pair(const float4 q0, const float4 q1, const float4 q2, float o_x, float o_y, float o_z, float i_x, float i_y, float i_z,
-                       float tbest, float tmin, bool& hl, bool& hr)
+                       float tbest, float tmin, bool& hl, bool& hr, float& tel, float& ter)
 {
   const v2f ox = {o_x, o_x}, oy = {o_y, o_y}, oz = {o_z, o_z};
   const v2f ix = {i_x, i_x}, iy = {i_y, i_y}, iz = {i_z, i_z};
@@ -119,9 +119,63 @@ MIRT_DEV void box_pair(const float4 q0, const float4 q1, const float4 q2, float 
   float te = fmaxf(fmaxf(fminf(lx.x, lx.y), fminf(ly.x, ly.y)), fminf(lz.x, lz.y));
   float tx = fminf(fminf(fmaxf(lx.x, lx.y), fmaxf(ly.x, ly.y)), fmaxf(lz.x, lz.y));
   hl = te < tx && te < tbest && tx > tmin;
+  tel = te;
   te = fmaxf(fmaxf(fminf(rx.x, rx.y), fminf(ry.x, ry.y)), fminf(rz.x, rz.y));
   tx = fminf(fminf(fmaxf(rx.x, rx.y), fmaxf(ry.x, ry.y)), fmaxf(rz.x, rz.y));
   hr = te < tx && te < tbest && tx > tmin;
+  ter = te;
+}
+
+// The descent order at a node whose children are both hit.  The reference goes left first (bvh_traversal.cu:149-157).  Where the
+// node's record allows it (NODE_SWAP_* & swap_mask) the child whose box the ray enters first is taken first instead: fewer
+// visits, the same closest hit (see closer_hit).  Returns the two references in visiting order.
+MIRT_DEV void order_children(bool hl, bool hr, float tel, float ter, uint32_t node_flags, uint32_t swap_mask, uint32_t& lref, uint32_t& rref)
+{
+  const bool swp = hl && hr && (node_flags & swap_mask) != 0u && ter < tel;
+  const uint32_t l = lref;
+  lref = swp ? rref : l;
+  rref = swp ? l : rref;
+}
+
+// intersect_leaf_primitives' acceptance test (bvh_traversal.cu:66-84): hit, t > 1e-6, closer than the best so far -- and, on an
+// exact tie in t, the primitive with the smaller sorted index wins.  The reference's left-first walk meets the primitives
+// in sorted order and keeps the first of a tie (strict <); primitive records are stored in sorted order, so comparing the
+// record offsets gives the same winner in whatever order the primitives are met.  (REF_NONE has offset bits 0: nothing
+// ties with "no hit yet".)
+MIRT_DEV bool closer_hit(bool hit, float t, float tbest, uint32_t off16, uint32_t refbest)
+{
+  return hit && t > 1e-6f && (t < tbest || (t == tbest && off16 < (refbest & REF_OFFMASK)));
+}
+
+// checkTriangleIntersectionSoA, struct.cu:111-163.  The early returns of the reference become one boolean: a wave with
+// several lanes here never skips the code anyway, and values computed past a failed test (a division by ~0, a barycentric of
+// a point behind the ray) are simply not selected.
+MIRT_DEV bool triangle_hit(const float4 q0, const float4 q1, const float4 q2, const f3& o, const f3& d, float& t)
+{
+  const f3 p0 = mk3(q0.x, q0.y, q0.z), nor = mk3(q0.w, q1.x, q1.y);
+  const float denom = dot(d, nor);
+  t = dot(p0 - o, nor) / denom;
+  const f3 ip = t * d + o;
+  const f3 e1 = mk3(q1.z, q1.w, q2.x), e2 = mk3(q2.y, q2.z, q2.w);
+  const float b1 = dot(e1, ip - p0);
+  const float b2 = dot(e2, ip - p0);
+  const float b0 = 1.0f - b1 - b2;
+  return !(fabsf(denom) < 1e-9f) && !(t <= EPSILON) && (b0 >= -EPSILON) && (b1 >= -EPSILON) && (b2 >= -EPSILON);
+}
+
+// checkSphereIntersectionSoA, struct.cu:64-109 (same remark)
+MIRT_DEV bool sphere_hit(const float4 q, const f3& o, const f3& d, float& t)
+{
+  const f3 c = mk3(q.x, q.y, q.z);
+  const float r = q.w;
+  const f3 cr0 = c - o;
+  const bool inside = (dot(cr0, cr0) < r * r);
+  const float tc = dot(cr0, d);
+  const f3 dv = o + (tc * d) - c;
+  const float d2 = dot(dv, dv);
+  const float toff = sqrtf((r * r) - d2);
+  t = inside ? (tc + toff) : (tc - toff);
+  return !(!inside && tc < 0.0f) && !(!inside && (r * r) < d2);
 }
 
 struct Counters { uint32_t samples, rays, shadow_rays, internal_visits, sphere_tests, tri_tests, mat_fetches, max_stack; };
@@ -281,17 +335,19 @@ MIRT_DEV int advance_core(const RenderArgs& a, Lane& S, Counters& cn, const long
     Mat nm;
     nm.color = mk3(0, 0, 0); nm.shininess = mk3(0, 0, 0); nm.trans = mk3(0, 0, 0); nm.ior = 1.458f; nm.roughness = 0.0f;
     if (use_bvh) {
+      // the hit primitive's record (heap, sorted order) and its index in the scene's arrays (for the material)
       const uint32_t off16 = S.refbest & REF_OFFMASK;
-      const uint32_t id = (S.refbest & REF_TRI) ? (off16 - a.tri_base / 16u) / 3u : off16 - a.sph_base / 16u;
+      const float4* rec = a.nodes + off16;
+      const uint32_t id = a.unit_prim[off16 - a.prim_base16] & 0x7fffffffu;
       Np = S.tbest * rd0 + ro0;
       if (S.refbest & REF_TRI) {
-        const float4 q0 = a.tris[3 * (size_t)id + 0], q1 = a.tris[3 * (size_t)id + 1];
+        const float4 q0 = rec[0], q1 = rec[1];
         const f3 nor = mk3(q0.w, q1.x, q1.y);
         const float denom = dot(rd0, nor);
         Nn = (denom < 0.0f) ? nor : -nor;
         nm = load_mat(a.mats, (uint32_t)a.num_spheres + id);
       } else {
-        const float4 s = a.spheres[id];
+        const float4 s = rec[0];
         const f3 c = mk3(s.x, s.y, s.z);
         const f3 cr0 = c - ro0;
         const bool inside = (dot(cr0, cr0) < s.w * s.w);
@@ -338,6 +394,10 @@ MIRT_DEV int advance_core(const RenderArgs& a, Lane& S, Counters& cn, const long
       const f3 one = mk3(1.0f, 1.0f, 1.0f);
       const f3 Sh = nm.shininess, T = nm.trans;
       const f3 K = (one - Sh) * (one - T);
+      // (a full pending list would drop the child: counted, and mirt_get_stats reports it as an error -- the list is sized for
+      // the deepest chain the scene's bounces / gi allow, so this does not happen)
+      if (has_gi && a.gi != 0 && S.gi_n != 0 && S.pc >= a.pending_slots) atomicAdd(a.overflow, 1ull);
+      if (XtransNZ && Xbounce > 0 && S.pc + ((has_gi && a.gi != 0 && S.gi_n != 0) ? 1 : 0) >= a.pending_slots) atomicAdd(a.overflow, 1ull);
       if (has_gi && a.gi != 0 && S.gi_n != 0 && S.pc < a.pending_slots) {
         const f3 w = (S.wt * K) * nm.color;
         float* e = a.pending + ((size_t)S.pc * PENDING_WORDS) * gthreads + gid;
@@ -437,6 +497,7 @@ MIRT_DEV void advance(const RenderArgs& a, Lane& S, Counters& cn, const long lon
   const int micro = advance_core<COUNT>(a, S, cn, gid, gthreads);
   if (micro == M_DONE) {
     a.samples[S.g] = make_float4(S.L.x, S.L.y, S.L.z, S.alpha);
+    if (S.steps & 0x80000000u) atomicAdd(a.overflow, 1ull);      // a traversal stack overflowed during this sample
     if (a.chunk_cost) atomicMax(&a.chunk_cost[S.g >> a.chunk_shift], S.steps);
     S.g = -1;
     S.trav = false;

@@ -373,55 +373,36 @@ __global__ void __launch_bounds__(WBLOCK, MIRT_WF_WAVES_PER_SIMD) wf_trace_kerne
       bool pop = false;
       if (leaf) {
         // intersect_leaf_primitives, bvh_traversal.cu:47-89
-        float t = 0.0f;
-        bool hit = false;
+        const uint32_t off16 = cur & REF_OFFMASK;
         if (tri) {
-          // checkTriangleIntersectionSoA, struct.cu:111-163
           if (COUNT) cn.tri_tests++;
-          const f3 p0 = mk3(q0.x, q0.y, q0.z), nor = mk3(q0.w, q1.x, q1.y);
-          const float denom = dot(d, nor);
-          if (!(fabsf(denom) < 1e-9f)) {
-            t = dot(p0 - o, nor) / denom;
-            if (!(t <= EPSILON)) {
-              const f3 ip = t * d + o;
-              const f3 e1 = mk3(q1.z, q1.w, q2.x), e2 = mk3(q2.y, q2.z, q2.w);
-              const float b1 = dot(e1, ip - p0);
-              const float b2 = dot(e2, ip - p0);
-              const float b0 = 1.0f - b1 - b2;
-              hit = (b0 >= -EPSILON) && (b1 >= -EPSILON) && (b2 >= -EPSILON);
-            }
+          float t;
+          const bool hit = triangle_hit(q0, q1, q2, o, d, t);
+          if (closer_hit(hit, t, tbest, off16, refbest)) {
+            tbest = t; refbest = cur;
+            if (shadow && tbest < limit) trav = false;      // any-hit exit (same boolean as draw.cu:347-352 / 365-370)
           }
         } else {
-          // checkSphereIntersectionSoA, struct.cu:64-109
           if (COUNT) cn.sphere_tests++;
-          const f3 c = mk3(q0.x, q0.y, q0.z);
-          const float r = q0.w;
-          const f3 cr0 = c - o;
-          const bool inside = (dot(cr0, cr0) < r * r);
-          const float tc = dot(cr0, d);
-          if (!(!inside && tc < 0.0f)) {
-            const f3 dv = o + (tc * d) - c;
-            const float d2 = dot(dv, dv);
-            if (!(!inside && (r * r) < d2)) {
-              const float toff = sqrtf((r * r) - d2);
-              t = inside ? (tc + toff) : (tc - toff);
-              hit = true;
-            }
+          float t;
+          const bool hit = sphere_hit(q0, o, d, t);
+          if (closer_hit(hit, t, tbest, off16, refbest)) {
+            tbest = t; refbest = cur;
+            if (shadow && tbest < limit) trav = false;
           }
-        }
-        if (hit && t > 1e-6f && t < tbest) {
-          tbest = t; refbest = cur;
-          if (shadow && tbest < limit) trav = false;      // any-hit exit (same boolean as draw.cu:347-352 / 365-370)
         }
         pop = trav;
       } else {
         if (COUNT) cn.internal_visits++;
         // hit_aabb_adapted, bvh_traversal.cu:11-44, on both children
         bool hl, hr;
-        box_pair(q0, q1, q2, o.x, o.y, o.z, inv.x, inv.y, inv.z, tbest, tmin, hl, hr);
-        const uint32_t lref = __float_as_uint(q3.x), rref = __float_as_uint(q3.y);
+        float tel, ter;
+        box_pair(q0, q1, q2, o.x, o.y, o.z, inv.x, inv.y, inv.z, tbest, tmin, hl, hr, tel, ter);
+        uint32_t lref = __float_as_uint(q3.x), rref = __float_as_uint(q3.y);
+        order_children(hl, hr, tel, ter, __float_as_uint(q3.z), a.swap_mask, lref, rref);
         if (hl && hr) {
           cur = lref;
+          if (sp >= STACK_TOTAL) atomicAdd(a.overflow, 1ull);
           if (sp < STACK_TOTAL) {
             if (sp > 0) {
               const int s2 = sp - 1;
@@ -486,8 +467,7 @@ __global__ void wf_reset_kernel(uint32_t* state, int pool)
 int wavefront_trace(MirtScene* sc, RenderCtx& cx, RenderArgs& a, bool count, hipStream_t stream, float* trace_ms)
 {
   const long long nsamples = a.num_samples;
-  int pool = 1 << 21;
-  if (const char* e = getenv("MIRT_WF_POOL")) { long v = atol(e); if (v >= 256 && v <= (1 << 24)) pool = (int)v; }
+  int pool = sc->opt.wf_pool;
   if ((long long)pool > nsamples) pool = (int)((nsamples + SBLOCK - 1) / SBLOCK * SBLOCK);
   pool = (pool + SBLOCK - 1) / SBLOCK * SBLOCK;
   const int nlights = a.num_suns + a.num_bulbs;
@@ -525,14 +505,14 @@ int wavefront_trace(MirtScene* sc, RenderCtx& cx, RenderArgs& a, bool count, hip
   }
   a.pending = cx.pending; a.pending_slots = pending_slots;
 
-  static int trace_blocks = 0;
-  if (!trace_blocks) {
+  if (!sc->wf_trace_blocks) {
     hipDeviceProp_t prop;
     MIRT_HIP(hipGetDeviceProperties(&prop, sc->device));
     int per_cu = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, wf_trace_kernel<false>, WBLOCK, 0) != hipSuccess || per_cu < 1) per_cu = 4;
-    trace_blocks = prop.multiProcessorCount * per_cu;
+    sc->wf_trace_blocks = prop.multiProcessorCount * per_cu;
   }
+  const int trace_blocks = sc->wf_trace_blocks;
   const size_t gthreads = (size_t)trace_blocks * WBLOCK;
   const size_t spill_need = (size_t)STACK_TOTAL * gthreads;
   if (cx.spill_cap < spill_need) {

@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define MIRT_VERSION 1
+#define MIRT_VERSION 2
 
 typedef enum MirtStatus {
   MIRT_OK = 0,
@@ -32,7 +32,7 @@ typedef enum MirtStatus {
   MIRT_ERR_ARG = 3,
   MIRT_ERR_HIP = 4,         /* any HIP runtime failure (CUDA_CHECK, main.cu:14-23) */
   MIRT_ERR_NO_DEVICE = 5,
-  MIRT_ERR_STATE = 6        /* e.g. render before build */
+  MIRT_ERR_STATE = 6        /* e.g. render before build; a capacity overflow reported by mirt_get_stats */
 } MirtStatus;
 
 /* ---- POD scene structs: same field order and size as the reference's classes -------------------- */
@@ -89,6 +89,26 @@ int mirt_scene_create(const MirtSceneDesc* desc, int device, MirtScene** out);
 /* freeRawConfigDeviceMemory, config_utils.cuh:20 (frees everything; the reference leaks the SoA arrays). */
 void mirt_scene_destroy(MirtScene* sc);
 
+/* Mode switches and tuning values of a scene, by name.  Not in the reference (its knobs are compile-time constants).
+ *   build (take effect at the next mirt_build_lbvh):
+ *     "bounds_as_shipped" 0/1 (default 0): 1 reproduces the shipped reference's tree -- scene bounds never stored
+ *                         (parse.cpp:28), every Morton code 0
+ *   render:
+ *     "traversal"         MIRT_TRAVERSAL_*: 0 the reference's left-first descent (bvh_traversal.cu:149-157); 1 (default)
+ *                         near-child-first at nodes whose subtrees hold spheres only -- same pixels, fewer visits;
+ *                         2 near-child-first everywhere (a triangle-silhouette sample may differ where the
+ *                         reference's own result depends on its visiting order)
+ *     "wavefront"         0/1: the trace/shade kernel pair instead of the single kernel
+ *     "stack_lds_depth", "refill_k", "batch_k", "leaf_k", "reps", "drain_lanes", "chunk_shift", "trace_waves", "sched",
+ *     "wf_pool", "wf_refill_k": tuning (defaults are the measured optima)
+ * Environment variables MIRT_<NAME> override the defaults once, when the scene is created; nothing reads the
+ * environment during a render. */
+#define MIRT_TRAVERSAL_REFERENCE 0
+#define MIRT_TRAVERSAL_ORDERED 1
+#define MIRT_TRAVERSAL_ORDERED_ALL 2
+int mirt_scene_set_option(MirtScene* sc, const char* name, int value);
+int mirt_scene_get_option(const MirtScene* sc, const char* name, int* value);
+
 /* build_lbvh_karas(RawConfig&, int morton_bits), lbvh_builder.cuh:14 / lbvh_builder.cu:401-521:
  * scene bounds -> 30-bit Morton codes -> stable radix sort -> Karras hierarchy -> AABB refit -> 64-byte
  * two-child node records.  Synchronous (like the reference, lbvh_builder.cu:475).  build_ms (nullable)
@@ -122,6 +142,10 @@ int mirt_scatter_part(const MirtRenderParams* p, const void* d_part_rgba8, void*
 typedef struct MirtStats {
   /* filled by a render with MIRT_RENDER_COUNTERS */
   uint64_t samples, rays, shadow_rays, internal_visits, sphere_tests, tri_tests, mat_fetches, max_stack;
+  /* capacity overflows of the frames finished since the previous call: a traversal stack deeper than the reference's 64
+   * entries (bvh_traversal.cu:8,154-164 prints a warning and drops the subtree) or a full pending-ray list.  Always
+   * counted; when non-zero mirt_get_stats fills the struct and returns MIRT_ERR_STATE -- the image is not trustworthy. */
+  uint64_t overflow_events;
   /* device time of the last render's trace kernel and of the whole render call, HIP events, ms */
   float trace_kernel_ms, render_ms;
   float build_ms;

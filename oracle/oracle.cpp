@@ -71,7 +71,7 @@ typedef struct {
 
 typedef struct {
   uint64_t samples, rays, shadow_rays, node_iters, internal_visits, sphere_tests, tri_tests,
-           mat_fetches, max_stack, prim_hits;
+           mat_fetches, max_stack, prim_hits, overflow;
 } OStats;
 
 typedef struct {
@@ -85,12 +85,16 @@ typedef struct {
 
 #define ORC_FLAG_ANYHIT_SHADOW 1u   /* shadow rays stop at the first occluder (same boolean as draw.cu:347-352,365-370) */
 #define ORC_FLAG_NORMAL_ZYX    2u   /* evaluate the three standerdD() arguments right-to-left (draw.cu:335-337 is unspecified) */
-/* experiment switches of the ordered traversal (traverse_x) */
-#define ORC_X_NEAR   16u   /* descend the nearer child first */
-#define ORC_X_CULL   32u   /* entry distance on the stack, re-tested on pop */
-#define ORC_X_PLANE  64u   /* closest-hit rays start with t_max = the plane hit distance */
-#define ORC_X_LE    128u   /* box rule t_enter <= t_max instead of < */
-#define ORC_X_ANY    (ORC_X_NEAR | ORC_X_CULL | ORC_X_PLANE | ORC_X_LE)
+/* Ordered traversal (the product's default; NOT in the reference, which always descends left first,
+ * bvh_traversal.cu:149-157).  Where both children of a node are hit and both subtrees hold spheres only, the child
+ * whose box the ray enters first is descended first; exact ties in the hit distance go to the primitive with the
+ * smaller sorted index, which is the one the left-first walk meets first.  For spheres the closest hit does not depend
+ * on the visiting order (a sphere is only ever hit inside its box), so pixels are those of the reference order and only
+ * the visit counters change.  Triangles are different: the reference accepts hits up to 0.001 (barycentric) outside a
+ * triangle, i.e. possibly outside its box, and whether such a hit is found depends on the order -- subtrees that hold
+ * a triangle are therefore walked in the reference order unless ORDERED_ALL is given. */
+#define ORC_FLAG_ORDERED       4u
+#define ORC_FLAG_ORDERED_ALL   8u   /* near child first at every node (triangle silhouettes may differ from the reference order) */
 
 /* ------------------------------------------------------------------------------------------------ */
 /* vec3 / RGB (vec3.cuh:7-107, struct.cuh:11-62)                                                     */
@@ -283,10 +287,10 @@ struct Scene {
   std::vector<ONode> nodes;         /* internal [0,N-2], leaves [N-1,2N-2] */
   float smin[3], smax[3];
   bool built;
-  std::vector<int> rfirst, rlast;   /* sorted-leaf range of every internal node (Karras) */
-  int collapse_k = 1;               /* experiment: subtrees with at most this many primitives are tested as one leaf */
-  int collapse_mixed = 1;
-  std::vector<uint8_t> collapsed;   /* per internal node */
+  /* ordered traversal: which subtrees hold spheres only */
+  std::vector<int> rfirst, rlast;   /* sorted-leaf range of every internal node (determine_range) */
+  std::vector<uint32_t> tris_before; /* [N+1]: number of triangles among sorted leaves [0, j) */
+  bool pure(int first, int last) const { return tris_before[(size_t)last + 1] == tris_before[(size_t)first]; }
 };
 
 struct AABB { float xmin, xmax, ymin, ymax, zmin, zmax; };
@@ -452,6 +456,8 @@ static int build(Scene& sc, int bounds_mode)
   const int total = 2 * N - 1;
   sc.nodes.assign(total, ONode());
   sc.rfirst.assign(N > 1 ? N - 1 : 0, 0); sc.rlast.assign(N > 1 ? N - 1 : 0, 0);
+  sc.tris_before.assign((size_t)N + 1, 0);
+  for (int i = 0; i < N; ++i) sc.tris_before[(size_t)i + 1] = sc.tris_before[(size_t)i] + (sc.refs[i].type != 0 ? 1u : 0u);
   std::vector<int> parent(total, -1);
   const uint32_t leaf_base = (uint32_t)(N - 1);
   /* initialize_leaf_nodes_kernel, lbvh_builder.cu:59-71 */
@@ -632,6 +638,7 @@ static Obj traverse(Ctx& cx, const Ray& ray, float initial_t_max, bool early, fl
     if (hl && hr) {
       cur = l;
       if (sp < 64) { stack[sp++] = r; if ((uint64_t)sp > cx.st.max_stack) cx.st.max_stack = (uint64_t)sp; }
+      else cx.st.overflow++;   /* the reference prints a warning and drops the subtree, bvh_traversal.cu:154-164 */
     } else if (hl) cur = l;
     else if (hr) cur = r;
     else {
@@ -642,7 +649,8 @@ static Obj traverse(Ctx& cx, const Ray& ray, float initial_t_max, bool early, fl
   return best;
 }
 
-static inline bool hit_aabb_t(const ONode& b, const V3& o, const V3& inv, float tmin, float tmax, float* te, bool le)
+/* hit_aabb_adapted as above, also returning the entry distance */
+static inline bool hit_aabb_t(const ONode& b, const V3& o, const V3& inv, float tmin, float tmax, float* te)
 {
   float tx1 = (b.xmin - o.x) * inv.x, tx2 = (b.xmax - o.x) * inv.x;
   float tnx = fminf(tx1, tx2), tfx = fmaxf(tx1, tx2);
@@ -653,65 +661,72 @@ static inline bool hit_aabb_t(const ONode& b, const V3& o, const V3& inv, float 
   float t_enter = fmaxf(fmaxf(tnx, tny), tnz);
   float t_exit = fminf(fminf(tfx, tfy), tfz);
   *te = t_enter;
-  return t_enter < t_exit && (le ? t_enter <= tmax : t_enter < tmax) && t_exit > tmin;
+  return t_enter < t_exit && t_enter < tmax && t_exit > tmin;
 }
 
-/* Experimental ordered traversal: same closest hit as traverse() (ties in t go to the smaller sorted-leaf index, which is
- * what the left-first walk finds first), fewer node visits. */
-static Obj traverse_x(Ctx& cx, const Ray& ray, float initial_t_max, bool early, float stop_below)
+/* traverse() with the product's near-child-first descent (see ORC_FLAG_ORDERED above): same closest hit as traverse(),
+ * fewer node visits. */
+static Obj traverse_ordered(Ctx& cx, const Ray& ray, float initial_t_max, bool early, float stop_below)
 {
   const Scene& sc = *cx.sc;
-  const uint32_t fl = cx.flags;
+  const bool order_pure = (cx.flags & (ORC_FLAG_ORDERED | ORC_FLAG_ORDERED_ALL)) != 0, order_all = (cx.flags & ORC_FLAG_ORDERED_ALL) != 0;
   Obj best = obj_none();
   best.distance = initial_t_max;
   float tmax = initial_t_max;
-  uint32_t best_leaf = 0xffffffffu;
+  bool have = false;
+  uint32_t best_leaf = 0;
   if (sc.nodes.empty()) return best;
   V3 inv = mk(1.0f / ray.dir.x, 1.0f / ray.dir.y, 1.0f / ray.dir.z);
   const float tmin = 0.0001f;
   const uint32_t N = (uint32_t)sc.refs.size();
-  uint32_t stack[64]; float stack_t[64];
+  uint32_t stack[64];
   int sp = 0;
   uint32_t cur = 0;
-  bool have = true;
-  while (have) {
+  while (true) {
     const ONode& node = sc.nodes[cur];
     cx.st.node_iters++;
-    uint32_t lf = 0, ll = 0; bool leaf = false;
-    if (node.count > 0) { leaf = true; lf = ll = node.prim_offset; }
-    else if (cur < N - 1 && !sc.collapsed.empty() && sc.collapsed[cur]) { leaf = true; lf = (uint32_t)sc.rfirst[cur]; ll = (uint32_t)sc.rlast[cur]; }
-    if (leaf) {
-      for (uint32_t k = lf; k <= ll; ++k) {
-        const OPrimRef& ref = sc.refs[k];
-        Obj h;
-        if (ref.type == 0) { h = check_sphere(cx, ray, ref.id); cx.st.sphere_tests++; }
-        else { h = check_triangle(cx, ray, ref.id); cx.st.tri_tests++; }
-        if (h.isHit && h.distance > 1e-6f && (h.distance < tmax || (h.distance == tmax && k < best_leaf))) {
-          tmax = h.distance; best = h; best_leaf = k;
-          if (early && best.distance < stop_below) return best;
-        }
+    if (node.count > 0) {
+      const uint32_t k = node.prim_offset;
+      const OPrimRef& ref = sc.refs[k];
+      Obj h;
+      if (ref.type == 0) { h = check_sphere(cx, ray, ref.id); cx.st.sphere_tests++; }
+      else { h = check_triangle(cx, ray, ref.id); cx.st.tri_tests++; }
+      if (h.isHit && h.distance > 1e-6f && (h.distance < tmax || (have && h.distance == tmax && k < best_leaf))) {
+        tmax = h.distance; best = h; best_leaf = k; have = true;
+        if (early && best.distance < stop_below) return best;
       }
-    } else {
-      cx.st.internal_visits++;
-      uint32_t l = node.left, r = node.right;
-      float tl, tr;
-      bool hl = hit_aabb_t(sc.nodes[l], ray.eye, inv, tmin, tmax, &tl, fl & ORC_X_LE);
-      bool hr = hit_aabb_t(sc.nodes[r], ray.eye, inv, tmin, tmax, &tr, fl & ORC_X_LE);
-      if (hl && hr) {
-        const bool swap = (fl & ORC_X_NEAR) && tr < tl;
-        cur = swap ? r : l;
-        if (sp < 64) { stack[sp] = swap ? l : r; stack_t[sp] = swap ? tl : tr; ++sp; if ((uint64_t)sp > cx.st.max_stack) cx.st.max_stack = (uint64_t)sp; }
-        continue;
-      } else if (hl) { cur = l; continue; }
-      else if (hr) { cur = r; continue; }
+      if (sp == 0) break;
+      cur = stack[--sp];
+      continue;
     }
-    have = false;
-    while (sp > 0) {
-      --sp;
-      if (!(fl & ORC_X_CULL) || ((fl & ORC_X_LE) ? stack_t[sp] <= tmax : stack_t[sp] < tmax)) { cur = stack[sp]; have = true; break; }
+    cx.st.internal_visits++;
+    uint32_t l = node.left, r = node.right;
+    float tl, tr;
+    bool hl = hit_aabb_t(sc.nodes[l], ray.eye, inv, tmin, tmax, &tl);
+    bool hr = hit_aabb_t(sc.nodes[r], ray.eye, inv, tmin, tmax, &tr);
+    if (hl && hr) {
+      bool swap = false;
+      if (order_pure && tr < tl) {
+        auto sub_pure = [&](uint32_t c) { return c >= N - 1 ? sc.refs[c - (N - 1)].type == 0 : sc.pure(sc.rfirst[c], sc.rlast[c]); };
+        swap = order_all || (sub_pure(l) && sub_pure(r));
+      }
+      cur = swap ? r : l;
+      if (sp < 64) { stack[sp++] = swap ? l : r; if ((uint64_t)sp > cx.st.max_stack) cx.st.max_stack = (uint64_t)sp; }
+      else cx.st.overflow++;
+    } else if (hl) cur = l;
+    else if (hr) cur = r;
+    else {
+      if (sp == 0) break;
+      cur = stack[--sp];
     }
   }
   return best;
+}
+
+static inline Obj traverse_any(Ctx& cx, const Ray& ray, float initial_t_max, bool early, float stop_below)
+{
+  if (cx.flags & (ORC_FLAG_ORDERED | ORC_FLAG_ORDERED_ALL)) return traverse_ordered(cx, ray, initial_t_max, early, stop_below);
+  return traverse(cx, ray, initial_t_max, early, stop_below);
 }
 
 /* checkPlane, draw.cu:581-615 */
@@ -744,16 +759,8 @@ static Obj hit_nearest(Ctx& cx, const Ray& ray, bool count_mat = true)
 {
   if (ray.bounce == 0) return obj_none();
   cx.st.rays++;
-  Obj b, p;
-  if (cx.flags & ORC_X_ANY) {
-    p = check_plane(cx, ray);
-    const bool bound = (cx.flags & ORC_X_PLANE) && p.isHit;
-    b = traverse_x(cx, ray, bound ? p.distance : INFINITY, false, -1.0f);
-    if (bound && !(b.distance < p.distance)) b.isHit = false;
-  } else {
-    b = traverse(cx, ray, INFINITY, false, -1.0f);
-    p = check_plane(cx, ray);
-  }
+  Obj b = traverse_any(cx, ray, INFINITY, false, -1.0f);
+  Obj p = check_plane(cx, ray);
   Obj r;
   if (b.isHit && p.isHit) r = (b.distance < p.distance) ? b : p;
   else if (b.isHit) r = b;
@@ -776,7 +783,7 @@ static bool occluded(Ctx& cx, const Ray& ray, float limit)
   cx.st.rays++;
   Obj p = check_plane(cx, ray);
   if (p.isHit && p.distance < limit) return true;
-  Obj b = (cx.flags & ORC_X_ANY) ? traverse_x(cx, ray, INFINITY, true, limit) : traverse(cx, ray, INFINITY, true, limit);
+  Obj b = traverse_any(cx, ray, INFINITY, true, limit);
   return b.isHit && b.distance < limit;
 }
 
@@ -1020,7 +1027,7 @@ static void stats_add(OStats* a, const OStats& b)
 {
   a->samples += b.samples; a->rays += b.rays; a->shadow_rays += b.shadow_rays; a->node_iters += b.node_iters;
   a->internal_visits += b.internal_visits; a->sphere_tests += b.sphere_tests; a->tri_tests += b.tri_tests;
-  a->mat_fetches += b.mat_fetches; a->prim_hits += b.prim_hits;
+  a->mat_fetches += b.mat_fetches; a->prim_hits += b.prim_hits; a->overflow += b.overflow;
   if (b.max_stack > a->max_stack) a->max_stack = b.max_stack;
 }
 
@@ -1109,21 +1116,6 @@ void* orc_scene_create(const OSceneDesc* d)
 void orc_scene_destroy(void* h) { delete (Scene*)h; }
 
 int orc_build_lbvh(void* h, int bounds_mode) { return build(*(Scene*)h, bounds_mode); }
-/* experiment: subtrees of at most k primitives (all of one type unless mixed) become one leaf of traverse_x */
-void orc_set_collapse(void* h, int k, int mixed)
-{
-  Scene& sc = *(Scene*)h;
-  const int N = (int)sc.refs.size();
-  sc.collapse_k = k; sc.collapse_mixed = mixed;
-  sc.collapsed.assign(N > 1 ? N - 1 : 0, 0);
-  for (int i = 0; i < N - 1; ++i) {
-    const int cnt = sc.rlast[i] - sc.rfirst[i] + 1;
-    if (cnt > k) continue;
-    bool ok = true;
-    if (!mixed) for (int j = sc.rfirst[i]; j <= sc.rlast[i]; ++j) if (sc.refs[j].type != sc.refs[sc.rfirst[i]].type) ok = false;
-    sc.collapsed[i] = ok;
-  }
-}
 int orc_num_nodes(void* h) { return (int)((Scene*)h)->nodes.size(); }
 void orc_get_nodes(void* h, ONode* out) { Scene* s = (Scene*)h; if (!s->nodes.empty()) memcpy(out, s->nodes.data(), s->nodes.size() * sizeof(ONode)); }
 void orc_get_codes(void* h, uint32_t* out) { Scene* s = (Scene*)h; if (!s->codes.empty()) memcpy(out, s->codes.data(), s->codes.size() * 4); }

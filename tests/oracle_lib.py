@@ -10,6 +10,11 @@ ORACLE_SO = os.path.join(ORACLE_DIR, "_build", "liboracle.so")
 
 FLAG_ANYHIT_SHADOW = 1
 FLAG_NORMAL_ZYX = 2
+FLAG_ORDERED = 4        # near child first where both subtrees hold spheres only (the product's default traversal)
+FLAG_ORDERED_ALL = 8    # near child first everywhere
+# what libmirt does by default: any-hit shadow rays, ordered traversal where pixels cannot change --
+# the oracle mirrors both so that the visit counters can be compared with ==
+PRODUCT_FLAGS = FLAG_ANYHIT_SHADOW | FLAG_ORDERED
 
 
 class V3(C.Structure):
@@ -34,7 +39,7 @@ NODE = np.dtype([("xmin", "<f4"), ("xmax", "<f4"), ("ymin", "<f4"), ("ymax", "<f
                  ("left", "<u4"), ("right", "<u4"), ("prim_offset", "<u4"), ("count", "<u4")])
 HIT = np.dtype([("t", "<f4"), ("kind", "<u4"), ("id", "<u4"), ("n", "<f4", 3)])
 STAT_FIELDS = ["samples", "rays", "shadow_rays", "node_iters", "internal_visits", "sphere_tests", "tri_tests",
-               "mat_fetches", "max_stack", "prim_hits"]
+               "mat_fetches", "max_stack", "prim_hits", "overflow"]
 
 
 class Stats(C.Structure):

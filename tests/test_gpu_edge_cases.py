@@ -13,9 +13,11 @@ import edge_scenes
 pytestmark = pytest.mark.gpu
 
 
-def run_case(text, w, h, spp):
+def run_case(text, w, h, spp, **options):
     stl = m.parseText(text)
     raw = m.initRawConfigFromStl(stl, 0)
+    for k, v in options.items():
+        raw.set_option(k, v)
     m.build_lbvh_karas(raw)
     p = api.render_params(w, h, spp, counters=True)
     img = torch.empty(w * h * 4, dtype=torch.uint8, device="cuda")
@@ -26,7 +28,7 @@ def run_case(text, w, h, spp):
     tree = raw.tree() if stl.num_prims > 0 else None
     raw.close()
     o = ol.OracleScene(pyscene.parse_lines(text.split("\n")), bounds_mode=0)
-    ref = o.render(w, h, spp, flags=ol.FLAG_ANYHIT_SHADOW, nthreads=8)
+    ref = o.render(w, h, spp, flags=ol.PRODUCT_FLAGS, nthreads=8)
     if tree is not None:
         on = o.nodes()
         for f in ("left", "right"):
@@ -53,15 +55,45 @@ def test_edge_scene_matches_oracle(name, spp):
         assert img[..., 3].max() == 255
 
 
-def test_stack_spill_path(monkeypatch):
+def test_stack_spill_path():
     """Stack depths beyond 32 LDS entries + the top-of-stack register need > 2^33 overlapping primitives in a balanced
-    Karras tree, so the spill path is forced instead: with MIRT_STACK_LDS_DEPTH=2 every entry below the top three goes
-    to the global spill area (max depth on this scene: 12).  Results and counters must not change."""
-    monkeypatch.setenv("MIRT_STACK_LDS_DEPTH", "2")
-    st, img = run_case(edge_scenes.deep_stack(3000), 24, 18, 4)
+    Karras tree, so the spill path is forced instead: with the option stack_lds_depth = 2 every entry below the top three
+    goes to the global spill area (max depth on this scene: 12).  Results and counters must not change."""
+    st, img = run_case(edge_scenes.deep_stack(3000), 24, 18, 4, stack_lds_depth=2)
     assert st["max_stack"] >= 10, st["max_stack"]
-    monkeypatch.setenv("MIRT_STACK_LDS_DEPTH", "0")
-    run_case(edge_scenes.deep_stack(500), 16, 12, 1)
+    run_case(edge_scenes.deep_stack(500), 16, 12, 1, stack_lds_depth=0)
+
+
+def test_options_are_validated():
+    stl = m.parseText(edge_scenes.single_sphere())
+    raw = m.initRawConfigFromStl(stl, 0)
+    assert raw.get_option("traversal") == 1 and raw.get_option("wavefront") == 0
+    for name, bad in (("reps", 9), ("traversal", 3), ("no_such_option", 1)):
+        with pytest.raises(m.MirtError) as e:
+            raw.set_option(name, bad)
+        assert e.value.status == 3
+    raw.close()
+
+
+def test_null_arrays_and_negative_counts_are_rejected():
+    """mirt_scene_create validates the descriptor instead of dereferencing it."""
+    import ctypes as C
+    stl = m.parseText(edge_scenes.single_sphere())
+    d = api.SceneDesc.from_buffer_copy(stl.desc)
+    d.spheres = None
+    h = C.c_void_p()
+    assert m.lib().mirt_scene_create(C.byref(d), 0, C.byref(h)) == 3 and not h.value
+    d = api.SceneDesc.from_buffer_copy(stl.desc)
+    d.num_planes = -1
+    assert m.lib().mirt_scene_create(C.byref(d), 0, C.byref(h)) == 3 and not h.value
+    p = api.render_params(16, 16, 5000)
+    raw = m.initRawConfigFromStl(stl, 0)
+    m.build_lbvh_karas(raw)
+    img = torch.empty(16 * 16 * 4, dtype=torch.uint8, device="cuda")
+    with pytest.raises(m.MirtError) as e:
+        m.render(img, 16, 16, 5000, raw, params=p)
+    assert e.value.status == 3
+    raw.close()
 
 
 def test_more_than_64_lights_is_rejected():

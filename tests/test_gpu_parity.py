@@ -9,6 +9,27 @@ import oracle_lib as ol
 
 pytestmark = pytest.mark.gpu
 
+
+class options:
+    """Temporarily set scene options on a (session-cached) device scene."""
+
+    def __init__(self, raw, rebuild=False, **kv):
+        self.raw, self.kv, self.rebuild = raw, kv, rebuild
+
+    def __enter__(self):
+        self.old = {k: self.raw.get_option(k) for k in self.kv}
+        for k, v in self.kv.items():
+            self.raw.set_option(k, v)
+        if self.rebuild:
+            m.build_lbvh_karas(self.raw)
+        return self.raw
+
+    def __exit__(self, *exc):
+        for k, v in self.old.items():
+            self.raw.set_option(k, v)
+        if self.rebuild:
+            m.build_lbvh_karas(self.raw)
+
 TOL = 1e-4   # north_star: output pixels within 1e-4 per channel (linear float RGBA before quantisation)
 
 
@@ -100,7 +121,7 @@ def test_small_frames_match_oracle(name, w, h, spp, gpu_scenes, oracle_scenes):
     stl, raw = gpu_scenes(name)
     gu8, gf = gpu_render(raw, w, h, spp, counters=True)
     st = raw.stats()
-    ref = oracle_scenes(name).render(w, h, spp, flags=ol.FLAG_ANYHIT_SHADOW, nthreads=8)
+    ref = oracle_scenes(name).render(w, h, spp, flags=ol.PRODUCT_FLAGS, nthreads=8)
     check_image(gu8, gf, ref)
     os_ = ref["stats"]
     for k in ("samples", "rays", "shadow_rays", "internal_visits", "sphere_tests", "tri_tests", "mat_fetches", "max_stack"):
@@ -116,7 +137,7 @@ def test_full_size_stripes_match_oracle(name, spp, gpu_scenes, oracle_scenes):
     part = 97
     gu8, gf = gpu_render(raw, w, h, spp, stripe_rows=rows, num_parts=parts, part=part)
     o = oracle_scenes(name)
-    refs = [o.render(w, h, spp, tile=(0, (part + j * parts) * rows, w, rows), flags=ol.FLAG_ANYHIT_SHADOW, nthreads=8) for j in range(3)]
+    refs = [o.render(w, h, spp, tile=(0, (part + j * parts) * rows, w, rows), flags=ol.PRODUCT_FLAGS, nthreads=8) for j in range(3)]
     ref = dict(f32=np.concatenate([r["f32"].reshape(-1, 4) for r in refs]), u8=np.concatenate([r["u8"].reshape(-1, 4) for r in refs]))
     check_image(gu8, gf, ref)
 
@@ -129,7 +150,7 @@ def test_config4_redchair_4k_64spp_stripes_match_oracle(gpu_scenes, oracle_scene
     part = 333
     gu8, gf = gpu_render(raw, w, h, spp, stripe_rows=rows, num_parts=parts, part=part)
     o = oracle_scenes("redchair")
-    refs = [o.render(w, h, spp, tile=(0, (part + j * parts) * rows, w, rows), flags=ol.FLAG_ANYHIT_SHADOW, nthreads=8) for j in range(2)]
+    refs = [o.render(w, h, spp, tile=(0, (part + j * parts) * rows, w, rows), flags=ol.PRODUCT_FLAGS, nthreads=8) for j in range(2)]
     ref = dict(f32=np.concatenate([r["f32"].reshape(-1, 4) for r in refs]), u8=np.concatenate([r["u8"].reshape(-1, 4) for r in refs]))
     check_image(gu8, gf, ref)
 
@@ -145,7 +166,7 @@ def test_config5_two_million_primitives_4k_256spp_stripe_matches_oracle():
     gu8, gf = gpu_render(raw, w, h, spp, stripe_rows=rows, num_parts=parts, part=part, counters=True)
     st = raw.stats()
     o = ol.OracleScene(ol.ArrayScene(stl), bounds_mode=0)
-    ref = o.render(w, h, spp, tile=(0, part, w, rows), flags=ol.FLAG_ANYHIT_SHADOW, nthreads=8)
+    ref = o.render(w, h, spp, tile=(0, part, w, rows), flags=ol.PRODUCT_FLAGS, nthreads=8)
     check_image(gu8, gf, ref)
     for k in ("samples", "rays", "shadow_rays", "internal_visits", "sphere_tests", "tri_tests", "mat_fetches", "max_stack"):
         assert st[k] == ref["stats"][k], (k, st[k], ref["stats"][k])
@@ -189,7 +210,7 @@ def test_synthetic_scene_build_and_render_match_oracle(ns, nt):
     w, h, spp = 96, 54, 4
     gu8, gf = gpu_render(raw, w, h, spp, counters=True)
     st = raw.stats()
-    ref = o.render(w, h, spp, flags=ol.FLAG_ANYHIT_SHADOW, nthreads=8)
+    ref = o.render(w, h, spp, flags=ol.PRODUCT_FLAGS, nthreads=8)
     check_image(gu8, gf, ref)
     for k in ("rays", "internal_visits", "sphere_tests", "tri_tests", "max_stack"):
         assert st[k] == ref["stats"][k], k
@@ -198,26 +219,77 @@ def test_synthetic_scene_build_and_render_match_oracle(ns, nt):
 
 
 @pytest.mark.parametrize("name,w,h,spp", [("tenthousand", 96, 54, 16), ("redchair", 64, 36, 32), ("spiral", 96, 54, 1), ("tri", 256, 256, 0)])
-def test_wavefront_path_matches_oracle(name, w, h, spp, gpu_scenes, oracle_scenes, monkeypatch):
-    """The trace/shade kernel pair (MIRT_WAVEFRONT=1) must give the same pixels and the same counters."""
-    monkeypatch.setenv("MIRT_WAVEFRONT", "1")
-    monkeypatch.setenv("MIRT_WF_POOL", "4096")      # small pool: many rounds, slots refilled many times
+def test_wavefront_path_matches_oracle(name, w, h, spp, gpu_scenes, oracle_scenes):
+    """The trace/shade kernel pair (option "wavefront") must give the same pixels and the same counters."""
     stl, raw = gpu_scenes(name)
-    gu8, gf = gpu_render(raw, w, h, spp, counters=True)
-    st = raw.stats()
-    ref = oracle_scenes(name).render(w, h, spp, flags=ol.FLAG_ANYHIT_SHADOW, nthreads=8)
+    with options(raw, wavefront=1, wf_pool=4096):      # small pool: many rounds, slots refilled many times
+        gu8, gf = gpu_render(raw, w, h, spp, counters=True)
+        st = raw.stats()
+    ref = oracle_scenes(name).render(w, h, spp, flags=ol.PRODUCT_FLAGS, nthreads=8)
     check_image(gu8, gf, ref)
     for k in ("samples", "rays", "shadow_rays", "internal_visits", "sphere_tests", "tri_tests", "mat_fetches", "max_stack"):
         assert st[k] == ref["stats"][k], (k, st[k], ref["stats"][k])
 
 
-def test_both_paths_give_identical_bytes(gpu_scenes, monkeypatch):
+def test_both_paths_give_identical_bytes(gpu_scenes):
     stl, raw = gpu_scenes("tenthousand")
-    monkeypatch.setenv("MIRT_WAVEFRONT", "0")
     a8, af = gpu_render(raw, 200, 120, 16)
-    monkeypatch.setenv("MIRT_WAVEFRONT", "1")
-    b8, bf = gpu_render(raw, 200, 120, 16)
+    with options(raw, wavefront=1):
+        b8, bf = gpu_render(raw, 200, 120, 16)
     assert np.array_equal(a8, b8) and np.array_equal(af.view(np.uint32), bf.view(np.uint32))
+
+
+COUNTER_KEYS = ("samples", "rays", "shadow_rays", "internal_visits", "sphere_tests", "tri_tests", "mat_fetches", "max_stack")
+
+
+@pytest.mark.parametrize("name,w,h,spp", [("tenthousand", 96, 54, 16), ("spiral", 96, 54, 4), ("redchair", 64, 36, 32), ("tri", 128, 128, 0)])
+@pytest.mark.parametrize("traversal", [0, 1, 2])
+def test_every_traversal_mode_matches_its_oracle_mirror(name, w, h, spp, traversal, gpu_scenes, oracle_scenes):
+    """traversal 0 = node for node the reference's left-first walk, 1 = near child first where both subtrees hold spheres
+    only (default), 2 = near child first everywhere.  The oracle mirrors each: pixels within tolerance, visit counters equal."""
+    stl, raw = gpu_scenes(name)
+    with options(raw, traversal=traversal):
+        gu8, gf = gpu_render(raw, w, h, spp, counters=True)
+        st = raw.stats()
+    flags = ol.FLAG_ANYHIT_SHADOW | {0: 0, 1: ol.FLAG_ORDERED, 2: ol.FLAG_ORDERED_ALL}[traversal]
+    ref = oracle_scenes(name).render(w, h, spp, flags=flags, nthreads=8)
+    check_image(gu8, gf, ref)
+    for k in COUNTER_KEYS:
+        assert st[k] == ref["stats"][k], (k, st[k], ref["stats"][k])
+
+
+@pytest.mark.parametrize("name", ["tenthousand", "spiral", "redchair", "tri"])
+def test_default_traversal_gives_the_bytes_of_the_reference_order(name, gpu_scenes):
+    """The ordered traversal changes which nodes are visited, never the closest hit: the whole 1920x1080 x 16 spp frame
+    (BASELINE configs 2 and 3) is byte-identical, float image included, to the frame rendered in the reference's left-first
+    order -- and it takes fewer node visits."""
+    stl, raw = gpu_scenes(name)
+    w, h, spp = 1920, 1080, 16
+    a8, af = gpu_render(raw, w, h, spp, counters=True)
+    sa = raw.stats()
+    with options(raw, traversal=0):
+        b8, bf = gpu_render(raw, w, h, spp, counters=True)
+        sb = raw.stats()
+    assert np.array_equal(a8, b8) and np.array_equal(af.view(np.uint32), bf.view(np.uint32))
+    assert sa["rays"] == sb["rays"] and sa["internal_visits"] <= sb["internal_visits"]
+    if name in ("tenthousand", "spiral"):
+        assert sa["internal_visits"] < 0.85 * sb["internal_visits"]
+
+
+def test_shipped_tree_mode_reproduces_the_survey_golden_image(gpu_scenes, oracle_scenes):
+    """Build option bounds_as_shipped: the reference as shipped never stores its scene bounds (parse.cpp:28), so every
+    Morton code is 0.  With it, and the reference's traversal order, the HIP path itself reproduces the RNG-free known
+    answer SURVEY.md 8c recorded from the reference's own code: tri.txt 256x256 aa 0, SHA-256 of the RGBA bytes."""
+    import hashlib
+    stl, raw = gpu_scenes("tri")
+    with options(raw, rebuild=True, bounds_as_shipped=1, traversal=0):
+        nodes, codes, refs, bounds = raw.tree()
+        gu8, gf = gpu_render(raw, 256, 256, 0)
+    o = oracle_scenes("tri", 1)
+    assert np.all(codes == 0) and np.array_equal(nodes["left"], o.nodes()["left"]) and np.array_equal(nodes["right"], o.nodes()["right"])
+    assert np.isposinf(bounds[:3]).all() and np.isneginf(bounds[3:]).all()
+    assert hashlib.sha256(gu8.tobytes()).hexdigest() == "ddfa3b865899303f54ad788218e8908fe5553b9ed4b085f9401dcabd19db64c9"
+    assert gu8.reshape(256, 256, 4)[164, 100].tolist() == [238, 238, 238, 255]      # the order-dependent pixel, as shipped
 
 
 def test_two_million_primitive_build_matches_oracle():
@@ -236,7 +308,7 @@ def test_two_million_primitive_build_matches_oracle():
     for f in ("xmin", "xmax", "ymin", "ymax", "zmin", "zmax"):
         assert np.array_equal(nodes[f].view(np.uint32), on[f].view(np.uint32)), f
     gu8, gf = gpu_render(raw, 64, 36, 1, counters=True)
-    ref = o.render(64, 36, 1, flags=ol.FLAG_ANYHIT_SHADOW, nthreads=8)
+    ref = o.render(64, 36, 1, flags=ol.PRODUCT_FLAGS, nthreads=8)
     check_image(gu8, gf, ref)
     raw.close()
     o.close()
