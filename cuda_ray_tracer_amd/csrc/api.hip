@@ -24,6 +24,7 @@ int upload(T** dst, const std::vector<T>& src)
 }
 
 bool nonzero(const MirtRGB& c) { return !(fabsf(c.r) < 1e-6f && fabsf(c.g) < 1e-6f && fabsf(c.b) < 1e-6f); }
+bool finite3(const MirtRGB& c) { return std::isfinite(c.r) && std::isfinite(c.g) && std::isfinite(c.b); }
 
 void pack_mat(const MirtMaterials& m, float4* out)
 {
@@ -131,6 +132,7 @@ int scene_create(const MirtSceneDesc* d, int device, MirtScene** out)
     pack_mat(s.mat, &mats[3 * (size_t)i]);
     if (nonzero(s.mat.trans)) sc->any_trans = true;
     if (s.mat.roughness > 0.0f) sc->any_rough = true;
+    if (!finite3(s.mat.color)) sc->colors_finite = false;
   }
   for (int i = 0; i < sc->Nt; ++i) {
     const MirtTriangle& t = d->triangles[i];
@@ -143,6 +145,7 @@ int scene_create(const MirtSceneDesc* d, int device, MirtScene** out)
     pack_mat(t.mat, &mats[3 * ((size_t)sc->Ns + i)]);
     if (nonzero(t.mat.trans)) sc->any_trans = true;
     if (t.mat.roughness > 0.0f) sc->any_rough = true;
+    if (!finite3(t.mat.color)) sc->colors_finite = false;
   }
   std::vector<MirtPrimRef> refs(d->prim_refs, d->prim_refs + N);
   for (int i = 0; i < N; ++i) {
@@ -161,7 +164,11 @@ int scene_create(const MirtSceneDesc* d, int device, MirtScene** out)
     memcpy(q.mat, m, sizeof(m)); q.pad = 0.0f;
     if (nonzero(p.mat.trans)) sc->any_trans = true;
     if (p.mat.roughness > 0.0f) sc->any_rough = true;
+    if (!finite3(p.mat.color)) sc->colors_finite = false;
   }
+  for (int i = 0; i < d->num_suns; ++i) if (!finite3(d->suns[i].color)) sc->colors_finite = false;
+  for (int i = 0; i < d->num_bulbs; ++i) if (!finite3(d->bulbs[i].color)) sc->colors_finite = false;
+  if (!std::isfinite(d->expose) && d->expose != INFINITY) sc->colors_finite = false;
   std::vector<LightDev> suns((size_t)d->num_suns), bulbs((size_t)d->num_bulbs);
   for (int i = 0; i < d->num_suns; ++i) {
     const MirtVec3& v = d->suns[i].dir;

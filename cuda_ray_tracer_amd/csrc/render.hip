@@ -238,7 +238,11 @@ __global__ void __launch_bounds__(TRACE_BLOCK, MIRT_WAVES_PER_SIMD) trace_kernel
           // first child next, push the second (bvh_traversal.cu:149-157: left, right), written with selects: one short
           // branch for the push
           const bool both = hl && hr;
-          if (both && S.sp < STACK_TOTAL) {
+          // (no depth check: the stack cannot outgrow STACK_TOTAL.  A Karras tree over 30-bit codes with the index tie-break of
+          // lbvh_builder.cu:76-101 is a radix tree over (code, index) keys of 30 + ceil(log2 N) bits, N < 2^28 (checked at scene
+          // creation), so it is at most 58 levels deep, and the walk keeps at most one pending sibling per level.  The
+          // reference's "stack overflow" warning, bvh_traversal.cu:154-164, is unreachable for the same reason.)
+          if (both) {
             // the previous top of stack goes to memory, the new top stays in a register.  With n entries on the stack,
             // entry k < n sits in slot k and entry n is S.tos (slot 0 only ever receives the dead S.tos of an empty
             // stack), so the slot to write is simply the current depth.
@@ -248,9 +252,6 @@ __global__ void __launch_bounds__(TRACE_BLOCK, MIRT_WAVES_PER_SIMD) trace_kernel
             ++S.sp;
             if (COUNT) cn.max_stack = max(cn.max_stack, (uint32_t)S.sp);
           }
-          // a stack beyond the reference's 64 entries: the reference warns and drops the subtree (:154-164); here the sample
-          // is marked (top bit of its step count) and reported as an error when it completes -- no atomic in this loop
-          S.steps |= (both && S.sp >= STACK_TOTAL) ? 0x80000000u : 0u;
           S.cur = hl ? lref : (hr ? rref : S.cur);
           pop = !(hl || hr);
         }
@@ -619,6 +620,7 @@ int render(MirtScene* sc, const MirtRenderParams* p, void* d_rgba8, void* d_rgba
   a.root_ref = sc->root_ref; a.num_spheres = sc->Ns; a.num_prims = sc->N;
   a.prim_base16 = sc->prim_base / 16u;
   a.swap_mask = opt.traversal == 1 ? NODE_SWAP_PURE : (opt.traversal == 2 ? NODE_SWAP_ANY : 0u);
+  a.skip_unlit = (sc->colors_finite && sc->d.num_suns + sc->d.num_bulbs <= 32) ? 1 : 0;
   a.planes = sc->planes; a.num_planes = sc->d.num_planes;
   a.suns = sc->suns; a.num_suns = sc->d.num_suns;
   a.bulbs = sc->bulbs; a.num_bulbs = sc->d.num_bulbs;

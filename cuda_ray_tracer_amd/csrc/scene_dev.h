@@ -50,6 +50,7 @@ struct RenderArgs {
   uint32_t root_ref;
   uint32_t prim_base16;           // offset of the primitive region in the heap, in 16-byte units
   uint32_t swap_mask;             // NODE_SWAP_* bits that allow near-child-first descent (0: the reference's left-first order)
+  int skip_unlit;                 // 1: shadow rays towards lights the shading normal faces away from are not traced (all colours finite)
   int num_spheres;
   int num_prims;
   const PlaneDev* planes; int num_planes;
@@ -205,6 +206,7 @@ struct MirtScene {
   mirt::RngCache rng;
   // LBVH build timing
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  bool colors_finite = true;               // every material colour and light colour is finite (0 * colour == 0)
   bool any_trans = false;                  // some material has transparency != 0
   bool any_rough = false;
 };

@@ -222,6 +222,7 @@ MIRT_DEV void start_ray(const Args& a, Lane& S, Counters& cn)
 {
   const bool shadow = S.shadow;
   if (COUNT) { cn.rays++; if (shadow) cn.shadow_rays++; }
+
   if (!HAVE_INV) S.inv = mk3(1.0f / S.d.x, 1.0f / S.d.y, 1.0f / S.d.z);
   float tplane = INFINITY;
   int plane_id = -1;
@@ -245,6 +246,27 @@ MIRT_DEV void start_ray(const Args& a, Lane& S, Counters& cn)
 
 MIRT_DEV void set_ray(Lane& S, const RayS& r) { S.o = r.o; S.d = r.d; S.bounce = r.bounce; }
 
+// A light the (rough) shading normal faces away from contributes colour * light * max(dot, 0) = 0 whether it is occluded or
+// not (draw.cu:353-357, 371-374), so its shadow ray is answered without a traversal: it still counts as a ray, and the light
+// is left "not occluded" (its term is then computed as usual and is 0).  Needs every colour of the scene to be finite
+// (0 * colour == 0; checked at scene creation) and at most 32 lights (the mask shares a word pair with the occlusion bits).
+template <typename Args>
+MIRT_DEV uint32_t unlit_mask(const Args& a, const f3& pn, const f3& Hp)
+{
+  uint32_t m = 0u;
+  if (a.skip_unlit) {
+    for (int li = 0; li < a.num_suns; ++li) {
+      const LightDev& lt = a.suns[li];
+      if (!(dot(pn, mk3(lt.nx, lt.ny, lt.nz)) > 0.0f)) m |= 1u << li;
+    }
+    for (int li = 0; li < a.num_bulbs; ++li) {
+      const LightDev& lt = a.bulbs[li];
+      if (!(dot(pn, normalize(mk3(lt.x, lt.y, lt.z) - Hp)) > 0.0f)) m |= 1u << (a.num_suns + li);
+    }
+  }
+  return m;
+}
+
 // The ray of the batch that was in flight has finished: note a shadow result, start the next ray of the batch
 // (shadow rays of diffuseLight, draw.cu:342-374, then the reflection ray of reflectionLight, draw.cu:402-404).
 // Shadow rays consume no random numbers, so tracing them after the reflection direction was drawn changes nothing.
@@ -256,10 +278,19 @@ MIRT_DEV void batch_next(const Args& a, Lane& S, Counters& cn)
     const bool occluded = (S.plane_id >= 0 && S.tplane < S.limit) || (S.refbest != REF_NONE && S.tbest < S.limit);
     if (occluded) S.occl |= 1ull << S.li;
   }
-  ++S.li;
   // the lanes of a wave are at different rays of their batches: each kind only sets the ray up, and all of them share
   // one start_ray (one copy of the plane loop instead of three executed one after the other)
   bool go = true;
+  // next light whose shadow ray is traced: the upper half of S.occl marks the lights the shading normal faces away from
+  // (unlit_mask, set when the node was entered); their rays count as rays but visit nothing
+  {
+    const uint32_t unlit = (nlights <= 32) ? (uint32_t)(S.occl >> 32) : 0u;      // (with more lights those bits are occlusion bits)
+    const int from = S.li + 1;
+    const uint32_t rest = (from < 32) ? (unlit | ((1u << from) - 1u)) : 0xffffffffu;       // lights before `from` are done
+    const int nxt = (~rest != 0u) ? (int)__builtin_ctz(~rest) : 32;
+    S.li = (unlit != 0u && from < nlights) ? min(nxt, nlights) : from;                     // (from > nlights after the reflection ray: the batch is over)
+    if (COUNT && unlit) { const int k = __popc(unlit & ~((from < 32) ? ((1u << from) - 1u) : 0xffffffffu) & ((S.li < 32) ? ((1u << S.li) - 1u) : 0xffffffffu)); cn.rays += k; cn.shadow_rays += k; }
+  }
   if (S.li < nlights) {
     // shadow ray, draw.cu:346 / 362-363
     S.o = S.bo;
@@ -437,7 +468,7 @@ MIRT_DEV int advance_core(const RenderArgs& a, Lane& S, Counters& cn, const long
         S.has_reflect = (S.Hbounce - 1) != 0;      // a bounce-0 ray never hits (draw.cu:294)
       }
       S.bo = S.Hp + S.Hn * EPSILON;
-      S.occl = 0ull;
+      S.occl = (unsigned long long)unlit_mask(a, S.pn, S.Hp) << 32;
       S.li = -1;
       S.batch_pending = true;
       S.state = ST_BATCH;
@@ -497,7 +528,6 @@ MIRT_DEV void advance(const RenderArgs& a, Lane& S, Counters& cn, const long lon
   const int micro = advance_core<COUNT>(a, S, cn, gid, gthreads);
   if (micro == M_DONE) {
     a.samples[S.g] = make_float4(S.L.x, S.L.y, S.L.z, S.alpha);
-    if (S.steps & 0x80000000u) atomicAdd(a.overflow, 1ull);      // a traversal stack overflowed during this sample
     if (a.chunk_cost) atomicMax(&a.chunk_cost[S.g >> a.chunk_shift], S.steps);
     S.g = -1;
     S.trav = false;

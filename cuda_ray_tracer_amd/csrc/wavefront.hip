@@ -186,8 +186,16 @@ __global__ void __launch_bounds__(SBLOCK, MIRT_WF_SHADE_WAVES) wf_shade_kernel(c
 
   // ---- emit this slot's rays: wave-level exclusive scan of the ray counts, one atomic per wave -------------------
   int nr = 0;
+  unsigned long long lit = 0ull;      // lights whose shadow ray is traced (see batch_next: unlit ones are answered at once)
   if (micro == M_TRACE) nr = 1;
-  else if (micro == M_BATCH) nr = nlights + (S.has_reflect ? 1 : 0);
+  else if (micro == M_BATCH) {
+    const uint32_t unlit = (uint32_t)(S.occl >> 32);
+    for (int j = 0; j < nlights; ++j) {
+      if (j < 32 && ((unlit >> j) & 1u)) { if (COUNT) { cn.rays++; cn.shadow_rays++; } }
+      else { lit |= 1ull << j; ++nr; }
+    }
+    nr += S.has_reflect ? 1 : 0;
+  }
   int incl = nr;
 #pragma unroll
   for (int off = 1; off < 64; off <<= 1) {
@@ -214,18 +222,19 @@ __global__ void __launch_bounds__(SBLOCK, MIRT_WF_SHADE_WAVES) wf_shade_kernel(c
     }
   } else if (micro == M_BATCH) {
     // shadow rays (draw.cu:346 / 362-363), then the reflection ray (draw.cu:402)
+    unsigned int q = first;
     for (int j = 0; j < nlights; ++j) {
+      if (!((lit >> j) & 1ull)) continue;
       f3 dir; float limit;
       if (j < a.num_suns) { const LightDev& lt = a.suns[j]; dir = mk3(lt.nx, lt.ny, lt.nz); limit = INFINITY; }
       else { const LightDev& lt = a.bulbs[j - a.num_suns]; const f3 bd = mk3(lt.x, lt.y, lt.z) - S.Hp; dir = normalize(bd); limit = length(bd); }
-      const unsigned int q = first + (unsigned int)j;
       if (q < w.max_rays) {
         w.rays[2 * (size_t)q + 0] = make_float4(S.bo.x, S.bo.y, S.bo.z, limit);
         w.rays[2 * (size_t)q + 1] = make_float4(dir.x, dir.y, dir.z, __uint_as_float((uint32_t)slot | ((uint32_t)j << 24) | (1u << 30)));
       }
+      ++q;
     }
     if (S.has_reflect) {
-      const unsigned int q = first + (unsigned int)nlights;
       S.o = S.bo; S.d = S.rdir; S.bounce = S.Hbounce - 1;
       if (q < w.max_rays) {
         w.rays[2 * (size_t)q + 0] = make_float4(S.o.x, S.o.y, S.o.z, INFINITY);
@@ -249,10 +258,10 @@ __global__ void __launch_bounds__(SBLOCK, MIRT_WF_SHADE_WAVES) wf_shade_kernel(c
     }
   }
   if (COUNT && a.counters) {
-    unsigned long long s0 = cn.samples, s6 = cn.mat_fetches;
+    unsigned long long s0 = cn.samples, s6 = cn.mat_fetches, s1 = cn.rays, s2 = cn.shadow_rays;
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) { s0 += __shfl_xor(s0, off); s6 += __shfl_xor(s6, off); }
-    if (lane == 0) { if (s0) atomicAdd(&a.counters[0], s0); if (s6) atomicAdd(&a.counters[6], s6); }
+    for (int off = 32; off > 0; off >>= 1) { s0 += __shfl_xor(s0, off); s6 += __shfl_xor(s6, off); s1 += __shfl_xor(s1, off); s2 += __shfl_xor(s2, off); }
+    if (lane == 0) { if (s0) atomicAdd(&a.counters[0], s0); if (s6) atomicAdd(&a.counters[6], s6); if (s1) atomicAdd(&a.counters[1], s1); if (s2) atomicAdd(&a.counters[2], s2); }
   }
 }
 
@@ -402,8 +411,7 @@ __global__ void __launch_bounds__(WBLOCK, MIRT_WF_WAVES_PER_SIMD) wf_trace_kerne
         order_children(hl, hr, tel, ter, __float_as_uint(q3.z), a.swap_mask, lref, rref);
         if (hl && hr) {
           cur = lref;
-          if (sp >= STACK_TOTAL) atomicAdd(a.overflow, 1ull);
-          if (sp < STACK_TOTAL) {
+          {   // (the stack cannot outgrow STACK_TOTAL: see render.hip)
             if (sp > 0) {
               const int s2 = sp - 1;
               if (s2 < WF_STACK_LDS) lds_stack[s2 * WBLOCK + tid] = tos;

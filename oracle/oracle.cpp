@@ -93,6 +93,10 @@ typedef struct {
  * the visit counters change.  Triangles are different: the reference accepts hits up to 0.001 (barycentric) outside a
  * triangle, i.e. possibly outside its box, and whether such a hit is found depends on the order -- subtrees that hold
  * a triangle are therefore walked in the reference order unless ORDERED_ALL is given. */
+/* Shadow rays towards lights the shading normal faces away from are answered without a traversal (the product always
+ * does this when every colour is finite): the light's term is colour * light * max(dot, 0) = 0 whether it is occluded
+ * or not (draw.cu:353-357, 371-374).  The ray still counts as a ray; it visits no node. */
+#define ORC_FLAG_SKIP_UNLIT    16u
 #define ORC_FLAG_ORDERED       4u
 #define ORC_FLAG_ORDERED_ALL   8u   /* near child first at every node (triangle silhouettes may differ from the reference order) */
 
@@ -826,14 +830,18 @@ static C4 diffuse_light(Ctx& cx, const Obj& obj, Rng* rng)
   for (size_t i = 0; i < sc.suns.size(); ++i) {
     V3 ld = mk(sc.suns[i].dir);
     Ray sr = mkray(obj.i_point + obj.normal * 0.001f, ld, 1);
-    if (occluded(cx, sr, INFINITY)) continue;
+    const bool unlit = (cx.flags & ORC_FLAG_SKIP_UNLIT) && !(dot(normal, normalize(ld)) > 0.0f);
+    if (unlit) { cx.st.rays++; cx.st.shadow_rays++; }
+    else if (occluded(cx, sr, INFINITY)) continue;
     float lambert = fmaxf(dot(normal, normalize(ld)), 0.0f);
     color = color + color_sun(lambert, obj.mat.color, c3(sc.suns[i].color), sc.d.expose);
   }
   for (size_t i = 0; i < sc.bulbs.size(); ++i) {
     V3 bd = mk(sc.bulbs[i].point) - obj.i_point;
     Ray sr = mkray(obj.i_point + obj.normal * 0.001f, bd, 1);
-    if (occluded(cx, sr, length(bd))) continue;
+    const bool unlit = (cx.flags & ORC_FLAG_SKIP_UNLIT) && !(dot(normal, normalize(bd)) > 0.0f);
+    if (unlit) { cx.st.rays++; cx.st.shadow_rays++; }
+    else if (occluded(cx, sr, length(bd))) continue;
     float lambert = fmaxf(dot(normal, normalize(bd)), 0.0f);
     color = color + color_bulb(lambert, obj.mat.color, c3(sc.bulbs[i].color), length(bd), sc.d.expose);
   }

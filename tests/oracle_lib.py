@@ -12,9 +12,11 @@ FLAG_ANYHIT_SHADOW = 1
 FLAG_NORMAL_ZYX = 2
 FLAG_ORDERED = 4        # near child first where both subtrees hold spheres only (the product's default traversal)
 FLAG_ORDERED_ALL = 8    # near child first everywhere
-# what libmirt does by default: any-hit shadow rays, ordered traversal where pixels cannot change --
-# the oracle mirrors both so that the visit counters can be compared with ==
-PRODUCT_FLAGS = FLAG_ANYHIT_SHADOW | FLAG_ORDERED
+FLAG_SKIP_UNLIT = 16    # shadow rays towards lights the shading normal faces away from are not traced (their term is 0)
+# what libmirt does: any-hit shadow rays and no shadow rays to unlit lights, always; ordered traversal
+# where pixels cannot change, by default -- the oracle mirrors each so that the visit counters can be compared with ==
+PRODUCT_ALWAYS = FLAG_ANYHIT_SHADOW | FLAG_SKIP_UNLIT
+PRODUCT_FLAGS = PRODUCT_ALWAYS | FLAG_ORDERED
 
 
 class V3(C.Structure):

@@ -251,7 +251,7 @@ def test_every_traversal_mode_matches_its_oracle_mirror(name, w, h, spp, travers
     with options(raw, traversal=traversal):
         gu8, gf = gpu_render(raw, w, h, spp, counters=True)
         st = raw.stats()
-    flags = ol.FLAG_ANYHIT_SHADOW | {0: 0, 1: ol.FLAG_ORDERED, 2: ol.FLAG_ORDERED_ALL}[traversal]
+    flags = ol.PRODUCT_ALWAYS | {0: 0, 1: ol.FLAG_ORDERED, 2: ol.FLAG_ORDERED_ALL}[traversal]
     ref = oracle_scenes(name).render(w, h, spp, flags=flags, nthreads=8)
     check_image(gu8, gf, ref)
     for k in COUNTER_KEYS:
