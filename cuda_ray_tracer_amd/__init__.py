@@ -4,8 +4,8 @@ Host side: api.py (ctypes over include/mirt.h).  Device side: csrc/*.hip, built 
 """
 from .api import (MirtError, StlConfig, RawConfig, parseInput, parseText, syntheticScene, initRawConfigFromStl,
                   copyConfigDataToDevice, freeRawConfigDeviceMemory, build_lbvh_karas, render, render_params,
-                  num_pixels, scatter_part, write_png, lib)
+                  num_pixels, scatter_part, write_png, lib, render_accumulate, finalize)
 
 __all__ = ["MirtError", "StlConfig", "RawConfig", "parseInput", "parseText", "syntheticScene", "initRawConfigFromStl",
            "copyConfigDataToDevice", "freeRawConfigDeviceMemory", "build_lbvh_karas", "render", "render_params",
-           "num_pixels", "scatter_part", "write_png", "lib"]
+           "num_pixels", "scatter_part", "write_png", "lib", "render_accumulate", "finalize"]

@@ -76,7 +76,7 @@ class TreeNode(C.Structure):
 EXPORTS = [
     "mirt_last_error", "mirt_version", "mirt_parse_scene_file", "mirt_parse_scene_text", "mirt_synthetic_scene",
     "mirt_host_scene_destroy", "mirt_host_scene_desc", "mirt_host_scene_filename", "mirt_scene_create",
-    "mirt_scene_destroy", "mirt_scene_set_option", "mirt_scene_get_option", "mirt_build_lbvh", "mirt_render_num_pixels", "mirt_render", "mirt_scatter_part",
+    "mirt_scene_destroy", "mirt_scene_set_option", "mirt_scene_get_option", "mirt_build_lbvh", "mirt_render_num_pixels", "mirt_render", "mirt_render_accumulate", "mirt_finalize", "mirt_scatter_part",
     "mirt_get_stats", "mirt_get_tree", "mirt_probe_math", "mirt_probe_xorwow", "mirt_write_png",
 ]
 
@@ -114,6 +114,8 @@ def lib():
     L.mirt_render_num_pixels.argtypes = [C.POINTER(RenderParams)]
     L.mirt_render_num_pixels.restype = C.c_int64
     L.mirt_render.argtypes = [C.c_void_p, C.POINTER(RenderParams), C.c_void_p, C.c_void_p, C.c_void_p]
+    L.mirt_render_accumulate.argtypes = [C.c_void_p, C.POINTER(RenderParams), C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+    L.mirt_finalize.argtypes = [C.POINTER(RenderParams), C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
     L.mirt_scatter_part.argtypes = [C.POINTER(RenderParams), C.c_void_p, C.c_void_p, C.c_void_p]
     L.mirt_get_stats.argtypes = [C.c_void_p, C.POINTER(Stats)]
     L.mirt_get_tree.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
@@ -309,6 +311,19 @@ def render(d_image, img_width, img_height, aa, raw, d_float=None, params=None, s
     if d_float is not None:
         f_ptr = d_float.data_ptr() if hasattr(d_float, "data_ptr") else int(d_float)
     _check(lib().mirt_render(raw._h, C.byref(p), C.c_void_p(img_ptr), C.c_void_p(f_ptr) if f_ptr else None, _stream_ptr(stream)))
+
+
+def render_accumulate(d_accum, img_width, img_height, sample_first, sample_count, raw, params=None, stream=None):
+    """render_kernel_atomic_aa, draw.cu:49-92: adds samples [sample_first, sample_first + sample_count) of every pixel to the
+    float32 accumulation buffer d_accum (num_pixels * 4, zeroed by the caller before the first call)."""
+    p = params if params is not None else render_params(img_width, img_height, max(sample_first + sample_count, 2))
+    _check(lib().mirt_render_accumulate(raw._h, C.byref(p), C.c_void_p(d_accum.data_ptr()), int(sample_first), int(sample_count), _stream_ptr(stream)))
+
+
+def finalize(d_image, d_accum, img_width, img_height, total_samples, params=None, stream=None):
+    """finalize_kernel, draw.cu:13-47: mean over total_samples, sRGB, 8-bit with rounding."""
+    p = params if params is not None else render_params(img_width, img_height, max(total_samples, 2))
+    _check(lib().mirt_finalize(C.byref(p), C.c_void_p(d_accum.data_ptr()), int(total_samples), C.c_void_p(d_image.data_ptr()), _stream_ptr(stream)))
 
 
 def scatter_part(params, d_part, d_frame, stream=None):

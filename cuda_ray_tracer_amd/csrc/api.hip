@@ -39,7 +39,7 @@ const OptionDesc OPTIONS[] = {
   {"traversal", &Options::traversal, 0, 2}, {"wavefront", &Options::wavefront, 0, 1},
   {"stack_lds_depth", &Options::stack_lds_depth, -1, 64}, {"refill_k", &Options::refill_k, 1, 64}, {"batch_k", &Options::batch_k, 1, 64},
   {"leaf_k", &Options::leaf_k, 1, 64}, {"reps", &Options::reps, 1, 8}, {"drain_lanes", &Options::drain_lanes, 0, 64},
-  {"chunk_shift", &Options::chunk_shift, 0, 12}, {"trace_waves", &Options::trace_waves, 0, 1 << 20}, {"sched", &Options::sched, 0, 1},
+  {"chunk_shift", &Options::chunk_shift, 0, 12}, {"trace_waves", &Options::trace_waves, 0, 1 << 20}, {"sched", &Options::sched, 0, 1}, {"slab_log2", &Options::slab_log2, 8, 30},
   {"wf_pool", &Options::wf_pool, 256, 1 << 24}, {"wf_refill_k", &Options::wf_refill_k, 1, 64},
 };
 
@@ -278,6 +278,19 @@ int mirt_render(MirtScene* sc, const MirtRenderParams* p, void* d_rgba8, void* d
   if (!sc || !p) { set_error("mirt_render: null argument"); return MIRT_ERR_ARG; }
   MIRT_HIP(hipSetDevice(sc->device));
   return render(sc, p, d_rgba8, d_rgba_f32, (hipStream_t)stream);
+}
+
+int mirt_render_accumulate(MirtScene* sc, const MirtRenderParams* p, void* d_accum_f32, int sample_first, int sample_count, void* stream)
+{
+  if (!sc || !p) { set_error("mirt_render_accumulate: null argument"); return MIRT_ERR_ARG; }
+  MIRT_HIP(hipSetDevice(sc->device));
+  return render_accumulate(sc, p, d_accum_f32, sample_first, sample_count, (hipStream_t)stream);
+}
+
+int mirt_finalize(const MirtRenderParams* p, const void* d_accum_f32, int total_samples, void* d_rgba8, void* stream)
+{
+  if (!p) { set_error("mirt_finalize: null argument"); return MIRT_ERR_ARG; }
+  return finalize(p, d_accum_f32, total_samples, d_rgba8, (hipStream_t)stream);
 }
 
 int mirt_scatter_part(const MirtRenderParams* p, const void* d_part_rgba8, void* d_frame_rgba8, void* stream)

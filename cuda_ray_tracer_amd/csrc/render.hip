@@ -33,6 +33,7 @@ namespace {
 
 constexpr int RBLOCK = 256;
 constexpr int MAX_SPP = 4096;         // resolve_kernel's partial-sum stack holds log2(4096) + 1 entries
+constexpr int MAX_SLAB_ARGS = 4;      // device copies of RenderArgs a context cycles through (one per slab in flight on its stream)
 // The trace kernel's waves never talk to each other, so a workgroup is one wave: a finished wave frees its slot (and its
 // 10 KB of LDS) at once instead of waiting for the slowest of four, which is what lets the next frame's waves move in
 // while this frame drains.
@@ -318,8 +319,15 @@ MIRT_DEV float4 mean_of(const float4 sum, int spp)
   return make_float4(sum.x * inv, sum.y * inv, sum.z * inv, sum.w * inv);
 }
 // pixel_color_accum / uchar conversion, draw.cu:191-205 (spp > 1) and draw.cu:120-135 (spp <= 1)
-MIRT_DEV void write_pixel(const ResolveArgs& a, long long lp, const float4 m)
+MIRT_DEV void write_pixel(const ResolveArgs& a, long long lq, const float4 sum)
 {
+  const long long lp = a.pixel_base + lq;
+  if (a.accum) {      // mirt_render_accumulate: one add per pixel and call
+    const float4 o = a.accum[lp];
+    a.accum[lp] = make_float4(o.x + sum.x, o.y + sum.y, o.z + sum.z, o.w + sum.w);
+    return;
+  }
+  const float4 m = a.count > 1 ? mean_of(sum, a.count) : sum;
   if (a.rgba_f32) a.rgba_f32[lp] = m;
   uchar4 o;
   if (a.spp <= 1) {
@@ -342,20 +350,20 @@ __global__ void __launch_bounds__(RBLOCK) resolve_kernel(const ResolveArgs a)
   const long long lp = (long long)blockIdx.x * RBLOCK + threadIdx.x;
   if (lp >= a.num_local_pixels) return;
   float4 m;
-  if (a.spp <= 1) {
+  if (a.count <= 1) {
     m = a.samples[lp];
   } else {
     // Sum in the order of `for (mask = P/2; mask > 0; mask /= 2) v += shfl_xor(v, mask)` as lane 0 sees it
     // (draw.cu:181-189), P = next power of two >= spp, absent samples = 0: a pairwise tree over the samples in
     // bit-reversed order.
     int P = 1, lg = 0;
-    while (P < a.spp) { P <<= 1; ++lg; }
-    const float4* s = a.samples + lp * a.spp;
+    while (P < a.count) { P <<= 1; ++lg; }
+    const float4* s = a.samples + lp * a.count;
     float4 stk[13];
     int top = 0;
     for (int i = 0; i < P; ++i) {
       const int idx = (int)(__brev((unsigned)i) >> (32 - lg));
-      float4 x = (idx < a.spp) ? s[idx] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+      float4 x = (idx < a.count) ? s[idx] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
       int j = i;
       while (j & 1) {
         --top;
@@ -365,7 +373,7 @@ __global__ void __launch_bounds__(RBLOCK) resolve_kernel(const ResolveArgs a)
       }
       stk[top++] = x;
     }
-    m = mean_of(stk[0], a.spp);
+    m = stk[0];
   }
   write_pixel(a, lp, m);
 }
@@ -383,14 +391,14 @@ __global__ void __launch_bounds__(TBLOCK) resolve_tree_kernel(const ResolveArgs 
   const int si = tid & (P - 1);
   const long long lp = (long long)blockIdx.x * ppb + (tid >> lg);
   float4 v = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-  if (lp < a.num_local_pixels && si < a.spp) v = a.samples[lp * a.spp + si];
+  if (lp < a.num_local_pixels && si < a.count) v = a.samples[lp * a.count + si];
   for (int mask = P >> 1; mask > 0; mask >>= 1) {
     v.x += __shfl_xor(v.x, mask); v.y += __shfl_xor(v.y, mask); v.z += __shfl_xor(v.z, mask); v.w += __shfl_xor(v.w, mask);
   }
   if (si == 0) sums[tid >> lg] = v;
   __syncthreads();
   const long long lq = (long long)blockIdx.x * ppb + tid;
-  if (tid < ppb && lq < a.num_local_pixels) write_pixel(a, lq, mean_of(sums[tid], a.spp));
+  if (tid < ppb && lq < a.num_local_pixels) write_pixel(a, lq, sums[tid]);
 }
 
 __global__ void __launch_bounds__(RBLOCK) scatter_kernel(const uchar4* __restrict__ part, uchar4* __restrict__ frame, long long n,
@@ -501,11 +509,14 @@ int64_t local_pixels(const MirtRenderParams* p)
 
 } // namespace
 
-int ensure_rng_tables(RngCache* rc, int spp, long long frame_pixels, hipStream_t stream, RngTablesDev* out)
+// sample_tables >= 1: tables of the sequence skips of sample indices [0, sample_tables) (curand_init(1234 + pixel, sample, 0));
+// 0: the per-pixel tables of curand_init(1234, pixel, 0).  allow_larger: tables for more sample indices serve as well.
+int ensure_rng_tables(RngCache* rc, int sample_tables, long long frame_pixels, hipStream_t stream, RngTablesDev* out, bool allow_larger)
 {
-  const long long key = spp > 1 ? (long long)spp : -frame_pixels;
-  if (rc->key != key) {
-    if (spp > 1) build_sample_tables(spp, rc->host);
+  const int spp = sample_tables;
+  const long long key = spp >= 1 ? (long long)spp : -frame_pixels;
+  if (rc->key != key && !(allow_larger && spp >= 1 && rc->key >= key)) {
+    if (spp >= 1) build_sample_tables(spp, rc->host);
     else build_pixel_tables(frame_pixels, 1234, rc->host);
     MIRT_HIP(hipDeviceSynchronize());   // another stream may still be reading the old tables
     rng_cache_free(rc);
@@ -537,31 +548,81 @@ static int grid_blocks(int device)
   return prop.multiProcessorCount * per_cu;
 }
 
-int render(MirtScene* sc, const MirtRenderParams* p, void* d_rgba8, void* d_rgba_f32, hipStream_t stream)
+#if MIRT_DIAG_PROF
+// diagnostic build only (tools/ab.py NAME -DMIRT_DIAG_PROF=1, MIRT_PROF=1): per-phase cycle stamps of the trace kernel
+static int report_prof(RenderCtx& cx, int blocks, hipStream_t stream)
 {
-  if (!sc->built) { set_error("mirt_render: call mirt_build_lbvh first"); return MIRT_ERR_STATE; }
-  const int64_t npix = local_pixels(p);
-  if (npix < 0 || p->spp < 0 || !d_rgba8) { set_error("mirt_render: bad parameters"); return MIRT_ERR_ARG; }
-  if (p->spp > MAX_SPP) { set_error("mirt_render: more than 4096 samples per pixel in one call"); return MIRT_ERR_ARG; }
-  if ((int64_t)p->width * p->height > 0x7fffffffll - 1234) { set_error("mirt_render: frame too large for the 32-bit pixel seed"); return MIRT_ERR_ARG; }
-  if (npix == 0) return MIRT_OK;
-  if ((long long)npix * (p->spp > 1 ? p->spp : 1) >= 0xffffffffll || (long long)p->stripe_rows * p->width >= 0x7fffffffll) {
-    set_error("mirt_render: more than 2^32 samples in one call; render the frame in parts"); return MIRT_ERR_ARG;
+  MIRT_HIP(hipStreamSynchronize(stream));
+  unsigned long long hh[16];
+  MIRT_HIP(hipMemcpy(hh, cx.prof, sizeof(hh), hipMemcpyDeviceToHost));
+  fprintf(stderr, "[mirt prof] waves=%llu cyc/wave=%.3g S=%.1f%% T=%.1f%% | T-iters/wave=%.0f active/iter=%.1f leaf-lanes/iter=%.1f | S-entries/wave=%.0f lanes/entry=%.1f | B-entries/wave=%.0f lanes/entry=%.1f\n",
+          hh[10], (double)hh[0] / hh[10], 100.0 * hh[1] / hh[0], 100.0 * hh[2] / hh[0], (double)hh[3] / hh[10], (double)hh[4] / (hh[3] ? hh[3] : 1), (double)hh[9] / (hh[3] ? hh[3] : 1),
+          (double)hh[5] / hh[10], (double)hh[6] / (hh[5] ? hh[5] : 1), (double)hh[7] / hh[10], (double)hh[8] / (hh[7] ? hh[7] : 1));
+  {
+    unsigned long long ad[4];
+    MIRT_HIP(hipMemcpy(ad, cx.prof + 16 + 3 * (size_t)blocks * (TRACE_BLOCK / 64), sizeof(ad), hipMemcpyDeviceToHost));
+    fprintf(stderr, "[mirt prof] shade phase: %.1f%% of it in the advance/batch loop (%.2f passes per entry), %.1f%% in init_sample, the rest in the chunk hand-out and the RNG / state moves\n",
+            100.0 * ad[0] / (hh[1] ? hh[1] : 1), (double)ad[1] / (hh[5] ? hh[5] : 1), 100.0 * ad[2] / (hh[1] ? hh[1] : 1));
+    fprintf(stderr, "[mirt prof] traversal phase: %.1f%% of it in the batch transitions of the loop header (batch_next + start_ray)\n", 100.0 * ad[3] / (hh[2] ? hh[2] : 1));
   }
-  const int sppe = p->spp > 1 ? p->spp : 1;
-  const long long nsamples = (long long)npix * sppe;
+  fprintf(stderr, "[mirt prof] after the queue is empty, per wave: %.0f iterations (%.1f lanes traversing, %.0f in drain mode), %.1f shade-phase entries\n",
+          (double)hh[11] / hh[10], (double)hh[15] / (hh[11] ? hh[11] : 1), (double)hh[14] / hh[10], (double)hh[12] / hh[10]);
+  {
+    const size_t nwaves = (size_t)blocks * (TRACE_BLOCK / 64);
+    std::vector<unsigned long long> w(3 * nwaves);
+    MIRT_HIP(hipMemcpy(w.data(), cx.prof + 16, w.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    unsigned long long t0 = ~0ull;
+    for (size_t i = 0; i < nwaves; ++i) if (w[3 * i] && w[3 * i] < t0) t0 = w[3 * i];
+    std::vector<double> st, ex, en;
+    for (size_t i = 0; i < nwaves; ++i) { st.push_back((w[3 * i] - t0) * 1e-5); ex.push_back(((w[3 * i + 1] ? w[3 * i + 1] : w[3 * i + 2]) - t0) * 1e-5); en.push_back((w[3 * i + 2] - t0) * 1e-5); }
+    std::sort(st.begin(), st.end()); std::sort(ex.begin(), ex.end()); std::sort(en.begin(), en.end());
+    auto q = [&](const std::vector<double>& v, double f) { return v[(size_t)(f * (v.size() - 1))]; };
+    fprintf(stderr, "[mirt prof] per-wave times, ms (min/10%%/50%%/90%%/max): start %.2f/%.2f/%.2f/%.2f/%.2f | queue empty %.2f/%.2f/%.2f/%.2f/%.2f | exit %.2f/%.2f/%.2f/%.2f/%.2f\n",
+            q(st, 0), q(st, .1), q(st, .5), q(st, .9), q(st, 1), q(ex, 0), q(ex, .1), q(ex, .5), q(ex, .9), q(ex, 1), q(en, 0), q(en, .1), q(en, .5), q(en, .9), q(en, 1));
+  }
+  return MIRT_OK;
+}
+#endif
+
+// One call of mirt_render / mirt_render_accumulate.  The part's pixels are rendered in slabs of at most 2^slab_log2 samples,
+// so the per-sample workspace is bounded (1 GiB by default) whatever the frame: BASELINE config 5 (3840x2160 x 256 spp,
+// 2.1 G samples) takes 32 slabs instead of a 34 GB buffer.  Each slab is a trace launch + a resolve launch; a slab boundary
+// costs one drain of the persistent grid (~1-2 ms per 64 M samples).
+//   d_accum == null: pixels are written (mean, sRGB, quantise);  sample_first must be 0 and sample_count max(spp, 1)
+//   d_accum != null: the sum of each pixel's samples [sample_first, sample_first + sample_count) is ADDED to d_accum
+static int render_impl(MirtScene* sc, const MirtRenderParams* p, void* d_rgba8, void* d_rgba_f32, void* d_accum, int sample_first,
+                       int sample_count, hipStream_t stream)
+{
+  const char* who = d_accum ? "mirt_render_accumulate" : "mirt_render";
+  if (!sc->built) { set_error(std::string(who) + ": call mirt_build_lbvh first"); return MIRT_ERR_STATE; }
+  const int64_t npix = local_pixels(p);
+  if (npix < 0 || p->spp < 0 || (!d_rgba8 && !d_accum)) { set_error(std::string(who) + ": bad parameters"); return MIRT_ERR_ARG; }
+  if (sample_first < 0 || sample_count < 1 || (long long)sample_first + sample_count > MAX_SPP) {
+    set_error(std::string(who) + ": more than 4096 samples per pixel (mirt_render_accumulate renders any number in several calls of at most 4096)"); return MIRT_ERR_ARG;
+  }
+  if ((int64_t)p->width * p->height > 0x7fffffffll - 1234) { set_error(std::string(who) + ": frame too large for the 32-bit pixel seed"); return MIRT_ERR_ARG; }
+  if (npix == 0) return MIRT_OK;
+  if (npix >= 0x7fffffffll || (long long)p->stripe_rows * p->width >= 0x7fffffffll) { set_error(std::string(who) + ": part too large"); return MIRT_ERR_ARG; }
+  const bool per_pixel_seed = d_accum != nullptr || p->spp > 1;      // draw.cu:74,162 vs draw.cu:105
+  const int sppe = sample_count;
+  const Options& opt = sc->opt;
+  // slabs: whole pixels, at most 2^slab_log2 samples each
+  long long slab_pixels = (1ll << opt.slab_log2) / sppe;
+  if (slab_pixels < 1) slab_pixels = 1;
+  if (slab_pixels > npix) slab_pixels = npix;
+  const int nslabs = (int)((npix + slab_pixels - 1) / slab_pixels);
+  const long long slab_samples_max = slab_pixels * sppe;
   const bool count = (p->flags & MIRT_RENDER_COUNTERS) != 0;
 
-  const Options& opt = sc->opt;
   if (!sc->grid_blocks) sc->grid_blocks = grid_blocks(sc->device);      // per scene, i.e. per device
   const int blocks_cached = sc->grid_blocks;
-  long long want_blocks = (nsamples + TRACE_BLOCK - 1) / TRACE_BLOCK;
+  long long want_blocks = (slab_samples_max + TRACE_BLOCK - 1) / TRACE_BLOCK;
   int blocks = (int)(want_blocks < blocks_cached ? want_blocks : blocks_cached);
   // A small frame (one GPU's stripe set of an 8-GPU job) rendered while another frame is in flight gets half the grid:
   // every wave ends with a drain -- its last samples, few live lanes, 0.5-2.5 ms -- during which it holds its slot, and
   // with two half-grid frames resident at a time there are half as many drains per frame (1/8 of 1080p x 16: 5.8 -> 5.4
   // ms per frame; no gain from 1/4 of a frame up, a loss for a frame rendered alone).
-  if (!count && blocks == blocks_cached && nsamples < 20ll * blocks_cached * TRACE_BLOCK) {
+  if (!count && blocks == blocks_cached && slab_samples_max < 20ll * blocks_cached * TRACE_BLOCK) {
     for (int i = 0; i < MIRT_MAX_FRAMES; ++i) {
       const RenderCtx& c = sc->ctx[i];
       if (c.used && c.stream != stream && hipEventQuery(c.ev3) == hipErrorNotReady) { blocks = blocks_cached > 1 ? blocks_cached / 2 : 1; break; }   // (a frame on this same stream does not overlap)
@@ -582,11 +643,11 @@ int render(MirtScene* sc, const MirtRenderParams* p, void* d_rgba8, void* d_rgba
     }
   }
   // workspace
-  if (cx.samples_cap < (size_t)nsamples) {
+  if (cx.samples_cap < (size_t)slab_samples_max) {
     MIRT_HIP(hipStreamSynchronize(stream));
     hipFree(cx.samples); cx.samples = nullptr; cx.samples_cap = 0;
-    MIRT_HIP(hipMalloc(&cx.samples, sizeof(float4) * (size_t)nsamples));
-    cx.samples_cap = (size_t)nsamples;
+    MIRT_HIP(hipMalloc(&cx.samples, sizeof(float4) * (size_t)slab_samples_max));
+    cx.samples_cap = (size_t)slab_samples_max;
   }
   const size_t spill_need = (size_t)STACK_TOTAL * gthreads;
   if (cx.spill_cap < spill_need) {
@@ -607,7 +668,8 @@ int render(MirtScene* sc, const MirtRenderParams* p, void* d_rgba8, void* d_rgba
 
   RenderArgs a;
   memset(&a, 0, sizeof(a));
-  a.width = p->width; a.height = p->height; a.bounces = sc->d.bounces; a.spp = p->spp; a.gi = sc->d.gi;
+  a.width = p->width; a.height = p->height; a.bounces = sc->d.bounces; a.gi = sc->d.gi;
+  a.spp = d_accum ? (p->spp > 1 ? p->spp : 2) : p->spp;      // only "is it >= 1" matters to the kernel: jittered samples (draw.cu:78-84,110-118,165-171)
   a.fisheye = sc->d.fisheye; a.panorama = sc->d.panorama;
   a.dof_focus = sc->d.dof_focus; a.dof_lens = sc->d.dof_lens; a.expose = sc->d.expose;
   a.forward.x = sc->d.forward.x; a.forward.y = sc->d.forward.y; a.forward.z = sc->d.forward.z;
@@ -615,7 +677,7 @@ int render(MirtScene* sc, const MirtRenderParams* p, void* d_rgba8, void* d_rgba
   a.up.x = sc->d.up.x; a.up.y = sc->d.up.y; a.up.z = sc->d.up.z;
   a.eye.x = sc->d.eye.x; a.eye.y = sc->d.eye.y; a.eye.z = sc->d.eye.z;
   a.stripe_rows = p->stripe_rows; a.num_parts = p->num_parts; a.part = p->part;
-  a.num_local_pixels = npix; a.num_samples = nsamples;
+  a.sample_first = sample_first; a.sample_count = sample_count; a.seed_per_pixel = per_pixel_seed ? 1 : 0;
   a.nodes = sc->nodes; a.unit_prim = sc->unit_prim; a.mats = sc->mats;
   a.root_ref = sc->root_ref; a.num_spheres = sc->Ns; a.num_prims = sc->N;
   a.prim_base16 = sc->prim_base / 16u;
@@ -625,9 +687,9 @@ int render(MirtScene* sc, const MirtRenderParams* p, void* d_rgba8, void* d_rgba
   a.suns = sc->suns; a.num_suns = sc->d.num_suns;
   a.bulbs = sc->bulbs; a.num_bulbs = sc->d.num_bulbs;
   // random numbers are consumed only by jitter (spp >= 1), depth of field, rough normals and GI
-  a.needs_rng = (p->spp >= 1) || (sc->d.dof_focus != 0.0f && !sc->d.fisheye && !sc->d.panorama) || sc->any_rough || sc->d.gi != 0;
+  a.needs_rng = (a.spp >= 1) || (sc->d.dof_focus != 0.0f && !sc->d.fisheye && !sc->d.panorama) || sc->any_rough || sc->d.gi != 0;
   if (a.needs_rng) {
-    int rc = ensure_rng_tables(&sc->rng, p->spp, (long long)p->width * p->height, stream, &a.rng);
+    int rc = ensure_rng_tables(&sc->rng, per_pixel_seed ? sample_first + sample_count : 0, (long long)p->width * p->height, stream, &a.rng, d_accum != nullptr);
     if (rc != MIRT_OK) return rc;
   }
   a.samples = cx.samples;
@@ -640,15 +702,18 @@ int render(MirtScene* sc, const MirtRenderParams* p, void* d_rgba8, void* d_rgba
   a.drain_lanes = opt.drain_lanes;
   a.batch_k = opt.batch_k;
 
-  // ---- longest-first chunk order (single-kernel path) ----------------------------------------------------------------
+  // ---- longest-first chunk order (single-kernel path, one-slab calls) ------------------------------------------------
   // chunk size: 256 samples, smaller for a small (part of a) frame so that every wave still gets a dozen chunks or more --
   // with four chunks per wave (1/8 of a 1080p frame) the waves finished up to a chunk apart
   int chunk_shift = MAX_CHUNK_SHIFT;
-  while (chunk_shift > MIN_CHUNK_SHIFT && (nsamples >> chunk_shift) < 16ll * blocks * (TRACE_BLOCK / 64)) --chunk_shift;
+  while (chunk_shift > MIN_CHUNK_SHIFT && (slab_samples_max >> chunk_shift) < 16ll * blocks * (TRACE_BLOCK / 64)) --chunk_shift;
   if (opt.chunk_shift >= 4) chunk_shift = opt.chunk_shift;
   a.chunk_shift = chunk_shift;
-  const size_t nchunks = (size_t)((nsamples + (1ll << chunk_shift) - 1) >> chunk_shift);
-  if (cx.chunk_cap < nchunks) {
+  const size_t nchunks = (size_t)((slab_samples_max + (1ll << chunk_shift) - 1) >> chunk_shift);
+  // (a call of several slabs has chunks to spare: no cost stamps, no order)
+  const bool wavefront = opt.wavefront != 0;
+  const bool sched = opt.sched != 0 && nslabs == 1 && !wavefront;
+  if (sched && cx.chunk_cap < nchunks) {
     MIRT_HIP(hipDeviceSynchronize());   // a frame on another stream may still be reading one of these orders
     hipFree(cx.chunk_cost); cx.chunk_cost = nullptr; cx.chunk_cap = 0; cx.order_key = -1;
     for (uint32_t*& o : cx.order_out) { hipFree(o); o = nullptr; }
@@ -657,9 +722,9 @@ int render(MirtScene* sc, const MirtRenderParams* p, void* d_rgba8, void* d_rgba
     cx.chunk_cap = nchunks;
   }
   // the newest finished frame with the same sample count (and chunk size) provides the order; a frame that is still running does not
-  const long long okey = nsamples * 16 + chunk_shift;
+  const long long okey = slab_samples_max * 16 + chunk_shift;
   const uint32_t* order = nullptr;
-  {
+  if (sched) {
     unsigned long long best = 0;
     for (int i = 0; i < MIRT_MAX_FRAMES; ++i) {
       RenderCtx& c = sc->ctx[i];
@@ -669,99 +734,81 @@ int render(MirtScene* sc, const MirtRenderParams* p, void* d_rgba8, void* d_rgba
     }
     if (!order && cx.used && cx.order_key == okey) order = cx.order_out[(cx.uses - 1) % RenderCtx::ORDER_BUFS];   // cx's own previous frame (finished: synchronised above)
   }
-  const bool sched = opt.sched != 0;
-  if (!sched) order = nullptr;
   a.chunk_order = order;
   a.chunk_cost = sched ? cx.chunk_cost : nullptr;
   cx.frame_id = ++sc->frame_seq;
   MIRT_HIP(hipEventRecord(cx.ev0, stream));
   if (sched) MIRT_HIP(hipMemsetAsync(cx.chunk_cost, 0, 4 * nchunks, stream));
   if (count) MIRT_HIP(hipMemsetAsync(cx.counters, 0, 8 * sizeof(unsigned long long), stream));
-  MIRT_HIP(hipMemsetAsync(cx.counters + 8, 0, sizeof(unsigned long long), stream));     // work counter ([9], the overflow events, is only reset by mirt_get_stats)
   a.work_counter = cx.counters + 8;
-  MIRT_HIP(hipEventRecord(cx.ev1, stream));
 #if MIRT_DIAG_PROF
-  const bool prof = getenv("MIRT_PROF") != nullptr;      // diagnostic build only (tools/ab.py NAME -DMIRT_DIAG_PROF=1)
+  const bool prof = getenv("MIRT_PROF") != nullptr;
 #else
   const bool prof = false;
 #endif
-  const bool wavefront = opt.wavefront != 0;
   cx.wf_trace_ms = -1.0f;
-  if (wavefront) {
-    a.refill_k = opt.wf_refill_k;
-    float tms = 0.0f;
-    int rc = wavefront_trace(sc, cx, a, count, stream, &tms);
-    if (rc != MIRT_OK) return rc;
-    cx.wf_trace_ms = tms;
-  } else {
-    HotArgs h;
-    h.nodes = a.nodes; h.root_ref = a.root_ref; h.swap_mask = a.swap_mask;
-    h.planes = a.planes; h.num_planes = a.num_planes; h.suns = a.suns; h.num_suns = a.num_suns; h.bulbs = a.bulbs; h.num_bulbs = a.num_bulbs;
-    h.stack_spill = a.stack_spill; h.lds_depth = a.lds_depth; h.refill_k = a.refill_k; h.batch_k = a.batch_k; h.drain_lanes = a.drain_lanes;
-    h.leaf_k = opt.leaf_k;
-    h.reps = opt.reps;
-    h.prof = nullptr;
-    if (!cx.args_dev) MIRT_HIP(hipMalloc(&cx.args_dev, sizeof(RenderArgs)));
-    if (prof) {
-      const size_t nwaves = (size_t)blocks * (TRACE_BLOCK / 64);
-      if (cx.prof) { hipFree(cx.prof); cx.prof = nullptr; }
-      MIRT_HIP(hipMalloc(&cx.prof, (20 + 3 * nwaves) * sizeof(unsigned long long)));
-      MIRT_HIP(hipMemsetAsync(cx.prof, 0, (20 + 3 * nwaves) * sizeof(unsigned long long), stream));
-      a.prof = cx.prof; h.prof = cx.prof;
-    }
-    MIRT_HIP(hipMemcpyAsync(cx.args_dev, &a, sizeof(RenderArgs), hipMemcpyHostToDevice, stream));
-#if MIRT_DIAG_PROF
-    if (prof) {
-      hipLaunchKernelGGL((trace_kernel<false, true>), dim3(blocks), dim3(TRACE_BLOCK), 0, stream, cx.args_dev, h);
-      MIRT_HIP(hipStreamSynchronize(stream));
-      unsigned long long hh[16];
-      MIRT_HIP(hipMemcpy(hh, cx.prof, sizeof(hh), hipMemcpyDeviceToHost));
-      fprintf(stderr, "[mirt prof] waves=%llu cyc/wave=%.3g S=%.1f%% T=%.1f%% | T-iters/wave=%.0f active/iter=%.1f leaf-lanes/iter=%.1f | S-entries/wave=%.0f lanes/entry=%.1f | B-entries/wave=%.0f lanes/entry=%.1f\n",
-              hh[10], (double)hh[0] / hh[10], 100.0 * hh[1] / hh[0], 100.0 * hh[2] / hh[0], (double)hh[3] / hh[10], (double)hh[4] / (hh[3] ? hh[3] : 1), (double)hh[9] / (hh[3] ? hh[3] : 1),
-              (double)hh[5] / hh[10], (double)hh[6] / (hh[5] ? hh[5] : 1), (double)hh[7] / hh[10], (double)hh[8] / (hh[7] ? hh[7] : 1));
-      {
-        unsigned long long ad[4];
-        MIRT_HIP(hipMemcpy(ad, cx.prof + 16 + 3 * (size_t)blocks * (TRACE_BLOCK / 64), sizeof(ad), hipMemcpyDeviceToHost));
-        fprintf(stderr, "[mirt prof] shade phase: %.1f%% of it in the advance/batch loop (%.2f passes per entry), %.1f%% in init_sample, the rest in the chunk hand-out and the RNG / state moves\n",
-                100.0 * ad[0] / (hh[1] ? hh[1] : 1), (double)ad[1] / (hh[5] ? hh[5] : 1), 100.0 * ad[2] / (hh[1] ? hh[1] : 1));
-        fprintf(stderr, "[mirt prof] traversal phase: %.1f%% of it in the batch transitions of the loop header (batch_next + start_ray)\n", 100.0 * ad[3] / (hh[2] ? hh[2] : 1));
-      }
-      fprintf(stderr, "[mirt prof] after the queue is empty, per wave: %.0f iterations (%.1f lanes traversing, %.0f in drain mode), %.1f shade-phase entries\n",
-              (double)hh[11] / hh[10], (double)hh[15] / (hh[11] ? hh[11] : 1), (double)hh[14] / hh[10], (double)hh[12] / hh[10]);
-      {
-        const size_t nwaves = (size_t)blocks * (TRACE_BLOCK / 64);
-        std::vector<unsigned long long> w(3 * nwaves);
-        MIRT_HIP(hipMemcpy(w.data(), cx.prof + 16, w.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
-        unsigned long long t0 = ~0ull;
-        for (size_t i = 0; i < nwaves; ++i) if (w[3 * i] && w[3 * i] < t0) t0 = w[3 * i];
-        std::vector<double> st, ex, en;
-        for (size_t i = 0; i < nwaves; ++i) { st.push_back((w[3 * i] - t0) * 1e-5); ex.push_back(((w[3 * i + 1] ? w[3 * i + 1] : w[3 * i + 2]) - t0) * 1e-5); en.push_back((w[3 * i + 2] - t0) * 1e-5); }
-        std::sort(st.begin(), st.end()); std::sort(ex.begin(), ex.end()); std::sort(en.begin(), en.end());
-        auto q = [&](const std::vector<double>& v, double f) { return v[(size_t)(f * (v.size() - 1))]; };
-        fprintf(stderr, "[mirt prof] per-wave times, ms (min/10%%/50%%/90%%/max): start %.2f/%.2f/%.2f/%.2f/%.2f | queue empty %.2f/%.2f/%.2f/%.2f/%.2f | exit %.2f/%.2f/%.2f/%.2f/%.2f\n",
-                q(st, 0), q(st, .1), q(st, .5), q(st, .9), q(st, 1), q(ex, 0), q(ex, .1), q(ex, .5), q(ex, .9), q(ex, 1), q(en, 0), q(en, .1), q(en, .5), q(en, .9), q(en, 1));
-      }
-    } else
-#endif
-    if (count) hipLaunchKernelGGL((trace_kernel<true, false>), dim3(blocks), dim3(TRACE_BLOCK), 0, stream, cx.args_dev, h);
-    else hipLaunchKernelGGL((trace_kernel<false, false>), dim3(blocks), dim3(TRACE_BLOCK), 0, stream, cx.args_dev, h);
+  float wf_ms_total = 0.0f;
+  HotArgs h;
+  h.nodes = a.nodes; h.root_ref = a.root_ref; h.swap_mask = a.swap_mask;
+  h.planes = a.planes; h.num_planes = a.num_planes; h.suns = a.suns; h.num_suns = a.num_suns; h.bulbs = a.bulbs; h.num_bulbs = a.num_bulbs;
+  h.stack_spill = a.stack_spill; h.lds_depth = a.lds_depth; h.refill_k = a.refill_k; h.batch_k = a.batch_k; h.drain_lanes = a.drain_lanes;
+  h.leaf_k = opt.leaf_k;
+  h.reps = opt.reps;
+  h.prof = nullptr;
+  if (!wavefront && !cx.args_dev) MIRT_HIP(hipMalloc(&cx.args_dev, sizeof(RenderArgs) * MAX_SLAB_ARGS));
+  if (prof) {
+    const size_t nwaves = (size_t)blocks * (TRACE_BLOCK / 64);
+    if (cx.prof) { hipFree(cx.prof); cx.prof = nullptr; }
+    MIRT_HIP(hipMalloc(&cx.prof, (20 + 3 * nwaves) * sizeof(unsigned long long)));
+    MIRT_HIP(hipMemsetAsync(cx.prof, 0, (20 + 3 * nwaves) * sizeof(unsigned long long), stream));
+    a.prof = cx.prof; h.prof = cx.prof;
   }
-  MIRT_HIP(hipGetLastError());
-  MIRT_HIP(hipEventRecord(cx.ev2, stream));
-
-  ResolveArgs ra;
-  ra.samples = cx.samples; ra.rgba8 = (unsigned char*)d_rgba8; ra.rgba_f32 = (float4*)d_rgba_f32;
-  ra.num_local_pixels = npix; ra.spp = p->spp;
   int P = 1, lg = 0;
-  while (P < p->spp) { P <<= 1; ++lg; }
-  if (p->spp > 1 && P <= 64) {
-    const long long ppb = TBLOCK >> lg;
-    hipLaunchKernelGGL(resolve_tree_kernel, dim3((unsigned)((npix + ppb - 1) / ppb)), dim3(TBLOCK), 0, stream, ra, P, lg);
-  } else {
-    hipLaunchKernelGGL(resolve_kernel, dim3((unsigned)((npix + RBLOCK - 1) / RBLOCK)), dim3(RBLOCK), 0, stream, ra);
+  while (P < sample_count) { P <<= 1; ++lg; }
+
+  MIRT_HIP(hipEventRecord(cx.ev1, stream));      // (ev1..ev2 brackets every slab's trace kernel; with several slabs also the resolves between them)
+  for (int slab = 0; slab < nslabs; ++slab) {
+    const long long p0 = (long long)slab * slab_pixels;
+    const long long pn = (p0 + slab_pixels < npix ? p0 + slab_pixels : npix) - p0;
+    a.pixel_base = p0; a.num_local_pixels = pn; a.num_samples = pn * sppe;
+    MIRT_HIP(hipMemsetAsync(cx.counters + 8, 0, sizeof(unsigned long long), stream));     // work counter ([9], the overflow events, is only reset by mirt_get_stats)
+    if (wavefront) {
+      a.refill_k = opt.wf_refill_k;
+      float tms = 0.0f;
+      int rc = wavefront_trace(sc, cx, a, count, stream, &tms);
+      if (rc != MIRT_OK) return rc;
+      wf_ms_total += tms;
+      cx.wf_trace_ms = wf_ms_total;
+    } else {
+      // this slab's arguments: the kernel reads them from device memory; a ring of copies, so that the copy for slab k + 1
+      // does not wait for the kernel of slab k (the stream orders a copy after the kernel that used the same slot)
+      RenderArgs* adev = cx.args_dev + (slab % MAX_SLAB_ARGS);
+      MIRT_HIP(hipMemcpyAsync(adev, &a, sizeof(RenderArgs), hipMemcpyHostToDevice, stream));
+#if MIRT_DIAG_PROF
+      if (prof) {
+        hipLaunchKernelGGL((trace_kernel<false, true>), dim3(blocks), dim3(TRACE_BLOCK), 0, stream, adev, h);
+        int rc = report_prof(cx, blocks, stream);
+        if (rc != MIRT_OK) return rc;
+      } else
+#endif
+      if (count) hipLaunchKernelGGL((trace_kernel<true, false>), dim3(blocks), dim3(TRACE_BLOCK), 0, stream, adev, h);
+      else hipLaunchKernelGGL((trace_kernel<false, false>), dim3(blocks), dim3(TRACE_BLOCK), 0, stream, adev, h);
+    }
+    MIRT_HIP(hipGetLastError());
+    if (slab == nslabs - 1) MIRT_HIP(hipEventRecord(cx.ev2, stream));
+
+    ResolveArgs ra;
+    ra.samples = cx.samples; ra.rgba8 = (unsigned char*)d_rgba8; ra.rgba_f32 = (float4*)d_rgba_f32; ra.accum = (float4*)d_accum;
+    ra.num_local_pixels = pn; ra.pixel_base = p0; ra.spp = p->spp; ra.count = sample_count;
+    if (sample_count > 1 && P <= 64) {
+      const long long ppb = TBLOCK >> lg;
+      hipLaunchKernelGGL(resolve_tree_kernel, dim3((unsigned)((pn + ppb - 1) / ppb)), dim3(TBLOCK), 0, stream, ra, P, lg);
+    } else {
+      hipLaunchKernelGGL(resolve_kernel, dim3((unsigned)((pn + RBLOCK - 1) / RBLOCK)), dim3(RBLOCK), 0, stream, ra);
+    }
+    MIRT_HIP(hipGetLastError());
   }
-  MIRT_HIP(hipGetLastError());
-  if (sched && !wavefront) {
+  if (sched) {
     // order for later frames.  It overwrites the buffer this context wrote three uses (12 frames) ago; every frame that
     // could have read that one has finished -- the host waited for each of them when it reused their contexts.
     uint32_t* out = cx.order_out[cx.uses % RenderCtx::ORDER_BUFS];
@@ -773,6 +820,43 @@ int render(MirtScene* sc, const MirtRenderParams* p, void* d_rgba8, void* d_rgba
   ++sc->frame_no;
   MIRT_HIP(hipEventRecord(cx.ev3, stream));
   cx.used = true; cx.counted = count; cx.timed = false; cx.stream = stream; sc->last = &cx;
+  return MIRT_OK;
+}
+
+int render(MirtScene* sc, const MirtRenderParams* p, void* d_rgba8, void* d_rgba_f32, hipStream_t stream)
+{
+  if (p->spp > MAX_SPP) { set_error("mirt_render: more than 4096 samples per pixel in one call (use mirt_render_accumulate + mirt_finalize)"); return MIRT_ERR_ARG; }
+  if (!d_rgba8) { set_error("mirt_render: bad parameters"); return MIRT_ERR_ARG; }
+  return render_impl(sc, p, d_rgba8, d_rgba_f32, nullptr, 0, p->spp > 1 ? p->spp : 1, stream);
+}
+
+// render_kernel_atomic_aa, draw.cu:49-92: adds the samples [sample_first, sample_first + sample_count) of every pixel of the
+// part to d_accum (float4 per pixel of the compact part buffer).  The reference adds sample by sample with atomicAdd, i.e. in
+// no particular order; here a call adds one value per pixel, the sum of its samples in the xor-butterfly order of draw.cu:181-189.
+int render_accumulate(MirtScene* sc, const MirtRenderParams* p, void* d_accum, int sample_first, int sample_count, hipStream_t stream)
+{
+  if (!d_accum) { set_error("mirt_render_accumulate: bad parameters"); return MIRT_ERR_ARG; }
+  return render_impl(sc, p, nullptr, nullptr, d_accum, sample_first, sample_count, stream);
+}
+
+__global__ void __launch_bounds__(RBLOCK) finalize_kernel_dev(const float4* __restrict__ accum, uchar4* __restrict__ rgba8, long long n, int aa)
+{
+  // finalize_kernel, draw.cu:13-47
+  const long long i = (long long)blockIdx.x * RBLOCK + threadIdx.x;
+  if (i >= n) return;
+  const float4 m = mean_of(accum[i], aa);
+  uchar4 o;
+  o.x = to_uchar_round(rgb_to_srgb(m.x)); o.y = to_uchar_round(rgb_to_srgb(m.y)); o.z = to_uchar_round(rgb_to_srgb(m.z)); o.w = to_uchar_round(m.w);
+  rgba8[i] = o;
+}
+
+int finalize(const MirtRenderParams* p, const void* d_accum, int total_samples, void* d_rgba8, hipStream_t stream)
+{
+  const int64_t n = local_pixels(p);
+  if (n < 0 || !d_accum || !d_rgba8 || total_samples < 1) { set_error("mirt_finalize: bad parameters"); return MIRT_ERR_ARG; }
+  if (n == 0) return MIRT_OK;
+  hipLaunchKernelGGL(finalize_kernel_dev, dim3((unsigned)((n + RBLOCK - 1) / RBLOCK)), dim3(RBLOCK), 0, stream, (const float4*)d_accum, (uchar4*)d_rgba8, (long long)n, total_samples);
+  MIRT_HIP(hipGetLastError());
   return MIRT_OK;
 }
 
@@ -807,7 +891,7 @@ int probe_xorwow(int device, int spp, int nstreams, int draws, uint32_t* out)
   MIRT_HIP(hipSetDevice(device));
   RngCache cache;
   RngTablesDev t;
-  int rc = ensure_rng_tables(&cache, spp, nstreams, nullptr, &t);
+  int rc = ensure_rng_tables(&cache, spp > 1 ? spp : 0, nstreams, nullptr, &t, false);
   if (rc != MIRT_OK) return rc;
   uint32_t* d = nullptr;
   MIRT_HIP(hipMalloc(&d, 4 * (size_t)nstreams * draws));

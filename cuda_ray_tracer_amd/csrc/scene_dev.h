@@ -40,8 +40,12 @@ struct RenderArgs {
   f3 forward, right, up, eye;
   // partition (MirtRenderParams)
   int stripe_rows, num_parts, part;
-  long long num_local_pixels;
-  long long num_samples;          // num_local_pixels * max(spp,1)
+  long long num_local_pixels;     // pixels of this launch (a slab of the call's part)
+  long long num_samples;          // num_local_pixels * samples per pixel of this launch
+  long long pixel_base;           // first local pixel of this launch within the call's compact part buffer
+  int sample_first;               // index of a pixel's first sample in this launch (0 for mirt_render; mirt_render_accumulate: any)
+  int sample_count;               // samples per pixel in this launch (max(spp, 1) for mirt_render)
+  int seed_per_pixel;             // 1: curand_init(1234 + pixel, sample, 0) (draw.cu:74,162); 0: curand_init(1234, pixel, 0) (draw.cu:105)
   // geometry
   const float4* nodes;            // record heap: 4 x float4 per internal node, then the primitive records in sorted order:
                                   // sphere (cx,cy,cz,r); triangle 3 x float4: p0.xyz nor.x | nor.yz e1.xy | e1.z e2.xyz
@@ -95,11 +99,14 @@ struct HotArgs {
 };
 
 struct ResolveArgs {
-  const float4* samples;
-  unsigned char* rgba8;
+  const float4* samples;          // this launch's samples: [num_local_pixels][count]
+  unsigned char* rgba8;           // the call's part buffer (nullable when accumulating)
   float4* rgba_f32;               // nullable
-  long long num_local_pixels;
-  int spp;
+  float4* accum;                  // non-null: add the per-pixel sample sums here instead of writing pixels (mirt_render_accumulate)
+  long long num_local_pixels;     // pixels of this launch
+  long long pixel_base;           // where they start in rgba8 / rgba_f32 / accum
+  int spp;                        // the call's spp (quantiser choice: draw.cu:129-132 for spp <= 1, :9-11,202-205 otherwise)
+  int count;                      // samples per pixel in `samples`
 };
 
 // device copies of the skip-ahead tables, keyed by spp (spp > 1) or by -(frame pixels) (spp <= 1)
@@ -122,6 +129,7 @@ struct Options {
   int chunk_shift = 0;         // 0: by frame size
   int trace_waves = 0;         // 0: fill the device
   int sched = 1;               // longest-first chunk order measured on earlier frames
+  int slab_log2 = 26;          // a call is rendered in slabs of at most 2^slab_log2 samples (1 GiB of per-sample workspace)
   int wf_pool = 1 << 21, wf_refill_k = 16;
 };
 
@@ -222,7 +230,9 @@ int scatter_part(const MirtRenderParams* p, const void* d_part, void* d_frame, h
 int64_t render_num_pixels(const MirtRenderParams* p);
 int probe_math(int device, int which, int n, const float* in, float* out);
 int probe_xorwow(int device, int spp, int nstreams, int draws, uint32_t* out);
-int ensure_rng_tables(RngCache* rc, int spp, long long frame_pixels, hipStream_t stream, RngTablesDev* out);
+int ensure_rng_tables(RngCache* rc, int sample_tables, long long frame_pixels, hipStream_t stream, RngTablesDev* out, bool allow_larger);
+int render_accumulate(MirtScene* sc, const MirtRenderParams* p, void* d_accum, int sample_first, int sample_count, hipStream_t stream);
+int finalize(const MirtRenderParams* p, const void* d_accum, int total_samples, void* d_rgba8, hipStream_t stream);
 void rng_cache_free(RngCache* rc);
 // wavefront.hip
 int wavefront_trace(MirtScene* sc, RenderCtx& cx, RenderArgs& a, bool count, hipStream_t stream, float* trace_ms);

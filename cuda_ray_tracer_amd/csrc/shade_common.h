@@ -528,7 +528,12 @@ MIRT_DEV void advance(const RenderArgs& a, Lane& S, Counters& cn, const long lon
   const int micro = advance_core<COUNT>(a, S, cn, gid, gthreads);
   if (micro == M_DONE) {
     a.samples[S.g] = make_float4(S.L.x, S.L.y, S.L.z, S.alpha);
-    if (a.chunk_cost) atomicMax(&a.chunk_cost[S.g >> a.chunk_shift], S.steps);
+    // scheduling statistic: the chunk's most expensive sample.  A plain (possibly stale, never too large) load first: most
+    // samples are not their chunk's maximum and issue no atomic (one atomic per sample was 0.76 GB of write traffic per frame)
+    if (a.chunk_cost) {
+      uint32_t* cc = &a.chunk_cost[S.g >> a.chunk_shift];
+      if (S.steps > *cc) atomicMax(cc, S.steps);
+    }
     S.g = -1;
     S.trav = false;
   } else if (micro == M_BATCH) {
@@ -544,12 +549,14 @@ MIRT_DEV void advance(const RenderArgs& a, Lane& S, Counters& cn, const long lon
 template <bool COUNT>
 MIRT_DEV void init_sample_core(const RenderArgs& a, Lane& S, Counters& cn, const long long idx)
 {
-  // sample -> local pixel -> frame pixel, in 32-bit arithmetic (render() guarantees num_samples < 2^32)
-  const uint32_t sppe = a.spp > 1 ? (uint32_t)a.spp : 1u;
+  // sample of this launch -> local pixel of the part -> frame pixel, in 32-bit arithmetic (a launch has < 2^31 samples, a
+  // part < 2^31 pixels: checked by render())
+  const uint32_t sppe = (uint32_t)a.sample_count;
   const uint32_t stripe_pixels = (uint32_t)a.stripe_rows * (uint32_t)a.width;
   const uint32_t i32 = (uint32_t)idx;
-  const uint32_t lp = i32 / sppe;
-  const int sidx = (int)(i32 - lp * sppe);
+  const uint32_t lq = i32 / sppe;                          // pixel within the launch
+  const uint32_t lp = (uint32_t)a.pixel_base + lq;         // pixel within the part
+  const int sidx = a.sample_first + (int)(i32 - lq * sppe);
   const uint32_t ls = lp / stripe_pixels;
   const uint32_t within = lp - ls * stripe_pixels;
   const uint32_t gs = ls * (uint32_t)a.num_parts + (uint32_t)a.part;
@@ -566,7 +573,7 @@ MIRT_DEV void init_sample_core(const RenderArgs& a, Lane& S, Counters& cn, const
   S.limit = INFINITY;
   S.shadow = false;
   S.batch_pending = false;
-  if (a.needs_rng) xw_init(S.rng, a.rng, pixel, (uint32_t)sidx);
+  if (a.needs_rng) xw_init(S.rng, a.rng, pixel, a.seed_per_pixel ? (uint32_t)sidx : 0u);
   float fx = (float)px, fy = (float)py;
   if (a.spp >= 1) {
     const float jx = randD(-0.5f, 0.5f, S.rng);

@@ -99,6 +99,8 @@ void mirt_scene_destroy(MirtScene* sc);
  *                         2 near-child-first everywhere (a triangle-silhouette sample may differ where the
  *                         reference's own result depends on its visiting order)
  *     "wavefront"         0/1: the trace/shade kernel pair instead of the single kernel
+ *     "slab_log2"         (default 26) a call is rendered in slabs of at most 2^slab_log2 samples: 16 B of workspace per
+ *                         sample, i.e. 1 GiB, however large the frame
  *     "stack_lds_depth", "refill_k", "batch_k", "leaf_k", "reps", "drain_lanes", "chunk_shift", "trace_waves", "sched",
  *     "wf_pool", "wf_refill_k": tuning (defaults are the measured optima)
  * Environment variables MIRT_<NAME> override the defaults once, when the scene is created; nothing reads the
@@ -135,6 +137,18 @@ int64_t mirt_render_num_pixels(const MirtRenderParams* p);
  * d_rgba8: num_pixels * 4 bytes, RGBA (pixel_t, libpng.h:23-27).  d_rgba_f32 (nullable): num_pixels * 4
  * floats, the linear RGBA sample mean before sRGB/quantisation (for parity checks). */
 int mirt_render(MirtScene* sc, const MirtRenderParams* p, void* d_rgba8, void* d_rgba_f32, void* stream);
+
+/* render_kernel_atomic_aa + finalize_kernel, draw.cu:13-92 (in the reference tree but not called by its render()): the
+ * accumulate / finalise pair for progressive rendering and for any number of samples per pixel.
+ * mirt_render_accumulate adds, for every pixel of the part, the samples [sample_first, sample_first + sample_count) to
+ * d_accum_f32 (num_pixels * 4 floats, zeroed by the caller before the first call); sample s of pixel p is seeded
+ * curand_init(1234 + p, s, 0) and jittered (draw.cu:74-84) whatever p->spp says.  The reference adds with atomicAdd, i.e. in
+ * no particular order; here one call adds one value per pixel -- the sum of its samples in the xor-butterfly order of
+ * draw.cu:181-189 -- so results do not depend on timing.  At most 4096 sample indices per call; any number over several calls.
+ * mirt_finalize writes the 8-bit image: mean over total_samples, sRGB, clamp * 255 + 0.5 (draw.cu:22-46).
+ * A single mirt_render_accumulate of samples [0, spp) followed by mirt_finalize gives the bytes of mirt_render (spp > 1). */
+int mirt_render_accumulate(MirtScene* sc, const MirtRenderParams* p, void* d_accum_f32, int sample_first, int sample_count, void* stream);
+int mirt_finalize(const MirtRenderParams* p, const void* d_accum_f32, int total_samples, void* d_rgba8, void* stream);
 
 /* Scatter a compact part buffer back into a full row-major frame (device to device). */
 int mirt_scatter_part(const MirtRenderParams* p, const void* d_part_rgba8, void* d_frame_rgba8, void* stream);

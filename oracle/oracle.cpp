@@ -1159,6 +1159,55 @@ int orc_render(void* h, int width, int height, int spp, int x0, int y0, int tw, 
   return 0;
 }
 
+/* render_kernel_atomic_aa, draw.cu:49-92, as the product's mirt_render_accumulate defines it: for every pixel of the tile the
+ * samples [first, first + count) (curand_init(1234 + pixel, s, 0), jittered) are summed in the xor-butterfly order over the
+ * next power of two >= count and the sum is ADDED to accum (tw*th*4 floats).  finalize_kernel (draw.cu:13-47) is
+ * orc_finalize. */
+int orc_render_accumulate(void* h, int width, int height, int x0, int y0, int tw, int th, int first, int count, float* accum,
+                          uint32_t flags, int nthreads)
+{
+  Scene* sc = (Scene*)h;
+  if (!sc->built || count < 1) return 1;
+  int P = 1; while (P < count) P <<= 1;
+#ifdef _OPENMP
+  if (nthreads < 1) nthreads = 1;
+  #pragma omp parallel for schedule(dynamic, 1) num_threads(nthreads)
+#endif
+  for (int ty = 0; ty < th; ++ty) {
+    Ctx cx; cx.sc = sc; cx.width = width; cx.height = height; cx.flags = flags; memset(&cx.st, 0, sizeof(cx.st));
+    for (int tx = 0; tx < tw; ++tx) {
+      const int px = x0 + tx, py = y0 + ty, pixel = py * width + px;
+      std::vector<C4> v((size_t)P, c4zero());
+      for (int s = 0; s < count; ++s) {
+        Rng rng;
+        rng_init(&rng, 1234ull + (uint64_t)pixel, (uint64_t)(first + s), 0);
+        float jx = randD(-0.5f, 0.5f, &rng);
+        float jy = randD(-0.5f, 0.5f, &rng);
+        v[(size_t)s] = shoot_primary(cx, (float)px + jx, (float)py + jy, &rng, NULL);
+      }
+      for (int mask = P / 2; mask > 0; mask /= 2) {
+        std::vector<C4> nv((size_t)P);
+        for (int l = 0; l < P; ++l) nv[(size_t)l] = v[(size_t)l] + v[(size_t)(l ^ mask)];
+        v.swap(nv);
+      }
+      float* a = accum + ((size_t)ty * tw + tx) * 4;
+      a[0] = a[0] + v[0].r; a[1] = a[1] + v[0].g; a[2] = a[2] + v[0].b; a[3] = a[3] + v[0].a;
+    }
+  }
+  (void)nthreads;
+  return 0;
+}
+void orc_finalize(const float* accum, int n, int aa, uint8_t* out)
+{
+  const float inv = 1.0f / (float)aa;
+  for (int i = 0; i < n; ++i) {
+    out[4 * i + 0] = float_to_uchar_round(rgb_to_srgb(accum[4 * i + 0] * inv));
+    out[4 * i + 1] = float_to_uchar_round(rgb_to_srgb(accum[4 * i + 1] * inv));
+    out[4 * i + 2] = float_to_uchar_round(rgb_to_srgb(accum[4 * i + 2] * inv));
+    out[4 * i + 3] = float_to_uchar_round(accum[4 * i + 3] * inv);
+  }
+}
+
 /* Strided sub-sample of a frame (every step-th pixel in x and y) for the bench's bounded CPU baseline. */
 int orc_render_subsample(void* h, int width, int height, int spp, int step, OStats* stats, uint32_t flags, int nthreads, float* checksum)
 {

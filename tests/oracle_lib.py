@@ -80,6 +80,10 @@ def lib():
                                  C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(Stats), C.c_uint32, C.c_int]
         L.orc_render_subsample.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(Stats), C.c_uint32,
                                            C.c_int, C.POINTER(C.c_float)]
+        L.orc_render_accumulate.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                            C.c_void_p, C.c_uint32, C.c_int]
+        L.orc_finalize.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+        L.orc_finalize.restype = None
         L.orc_xorwow_seq.argtypes = [C.c_uint64, C.c_uint64, C.c_uint64, C.c_int, C.c_void_p]
         L.orc_xorwow_state.argtypes = [C.c_uint64, C.c_uint64, C.c_void_p]
         L.orc_xorwow_floats.argtypes = [C.c_uint64, C.c_uint64, C.c_int, C.c_int, C.c_void_p]
@@ -168,6 +172,18 @@ class OracleScene:
                               aov.ctypes.data if want_aov else None, C.byref(st), flags, nthreads)
         assert rc == 0
         return dict(f32=f, u8=u, aov=aov, stats=st.as_dict())
+
+    def render_accumulate(self, accum, width, height, first, count, tile=None, flags=0, nthreads=1):
+        """Adds samples [first, first + count) of every pixel of the tile to accum ([th, tw, 4] float32, in place)."""
+        x0, y0, tw, th = tile if tile else (0, 0, width, height)
+        assert accum.shape == (th, tw, 4) and accum.dtype == np.float32 and accum.flags["C_CONTIGUOUS"]
+        assert lib().orc_render_accumulate(self.h, width, height, x0, y0, tw, th, first, count, accum.ctypes.data, flags, nthreads) == 0
+
+    @staticmethod
+    def finalize(accum, total):
+        out = np.zeros(accum.shape[:-1] + (4,), np.uint8)
+        lib().orc_finalize(np.ascontiguousarray(accum).ctypes.data, accum.size // 4, total, out.ctypes.data)
+        return out
 
     def render_subsample(self, width, height, spp, step, flags=0, nthreads=1):
         st = Stats()

@@ -353,3 +353,57 @@ def test_frames_in_flight_and_chunk_order_do_not_change_pixels(gpu_scenes):
         assert np.array_equal(b.cpu().numpy().reshape(-1, 4), ref8), i
     st = raw.stats()
     assert st["frames_timed"] >= 1 and st["trace_kernel_ms_mean"] > 0
+
+
+def test_slabs_do_not_change_pixels_or_counters(gpu_scenes):
+    """A call is rendered in slabs of at most 2^slab_log2 samples (bounded per-sample workspace: BASELINE config 5 would
+    otherwise need 34 GB).  Forced here on a small frame (2^10 samples per slab -> 169 slabs, ragged last one)."""
+    stl, raw = gpu_scenes("redchair")
+    w, h, spp = 120, 90, 16
+    a8, af = gpu_render(raw, w, h, spp, counters=True)
+    sa = raw.stats()
+    with options(raw, slab_log2=10):
+        b8, bf = gpu_render(raw, w, h, spp, counters=True)
+        sb = raw.stats()
+        c8, cf = gpu_render(raw, w, h, spp, stripe_rows=4, num_parts=3, part=1)
+    assert np.array_equal(a8, b8) and np.array_equal(af.view(np.uint32), bf.view(np.uint32))
+    for k in COUNTER_KEYS:
+        assert sa[k] == sb[k], k
+    d8, df = gpu_render(raw, w, h, spp, stripe_rows=4, num_parts=3, part=1)
+    assert np.array_equal(c8, d8) and np.array_equal(cf.view(np.uint32), df.view(np.uint32))
+
+
+def gpu_accumulate(raw, w, h, passes, total):
+    acc = torch.zeros(w * h * 4, dtype=torch.float32, device="cuda")
+    for first, count in passes:
+        m.render_accumulate(acc, w, h, first, count, raw)
+    img = torch.empty(w * h * 4, dtype=torch.uint8, device="cuda")
+    m.finalize(img, acc, w, h, total)
+    torch.cuda.synchronize()
+    return img.cpu().numpy().reshape(h, w, 4), acc.cpu().numpy().reshape(h, w, 4)
+
+
+@pytest.mark.parametrize("name,w,h,spp", [("tenthousand", 96, 54, 16), ("redchair", 64, 36, 32), ("spiral", 48, 27, 20)])
+def test_accumulate_then_finalize_gives_the_bytes_of_render(name, w, h, spp, gpu_scenes):
+    """render_kernel_atomic_aa + finalize_kernel (draw.cu:13-92) as mirt_render_accumulate + mirt_finalize: all samples in one
+    call is the same sum tree as mirt_render -> identical bytes."""
+    stl, raw = gpu_scenes(name)
+    r8, rf = gpu_render(raw, w, h, spp)
+    a8, acc = gpu_accumulate(raw, w, h, [(0, spp)], spp)
+    assert np.array_equal(a8.reshape(-1, 4), r8)
+
+
+@pytest.mark.parametrize("name,w,h,passes", [("tenthousand", 64, 36, [(0, 8), (8, 8), (16, 5)]), ("redchair", 48, 27, [(0, 1), (1, 1), (2, 30)]),
+                                             ("tri", 40, 40, [(0, 100), (100, 100)])])
+def test_progressive_accumulation_matches_the_oracle(name, w, h, passes, gpu_scenes, oracle_scenes):
+    """Several calls (progressive rendering; more than 64 samples per pixel): every call adds its own butterfly-ordered sum.
+    The oracle does the same arithmetic: accumulation buffer within the float tolerance, 8-bit image within 1 LSB."""
+    stl, raw = gpu_scenes(name)
+    total = sum(c for _, c in passes)
+    g8, gacc = gpu_accumulate(raw, w, h, passes, total)
+    o = oracle_scenes(name)
+    oacc = np.zeros((h, w, 4), np.float32)
+    for first, count in passes:
+        o.render_accumulate(oacc, w, h, first, count, flags=ol.PRODUCT_FLAGS, nthreads=8)
+    assert np.nanmax(np.abs(gacc.astype(np.float64) - oacc.astype(np.float64))) <= TOL * total
+    assert np.abs(g8.astype(np.int32) - ol.OracleScene.finalize(oacc, total).astype(np.int32)).max() <= 1

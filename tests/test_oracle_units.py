@@ -164,3 +164,18 @@ def test_struct_sizes_match_the_reference():
     want = {0: 44, 1: 60, 2: 116, 3: 84, 4: 24, 5: 8}
     for k, v in want.items():
         assert ol.lib().orc_sizeof(k) == v
+
+
+def test_accumulate_in_one_pass_equals_render(oracle_scenes):
+    """orc_render_accumulate + orc_finalize (render_kernel_atomic_aa + finalize_kernel, draw.cu:13-92) over all samples at once
+    is the same sum tree as the warp kernel (draw.cu:135-213): identical 8-bit image; two passes agree within rounding."""
+    o = oracle_scenes("tenthousand")
+    w, h, spp = 40, 24, 16
+    r = o.render(w, h, spp, nthreads=8)
+    acc = np.zeros((h, w, 4), np.float32)
+    o.render_accumulate(acc, w, h, 0, spp, nthreads=8)
+    assert np.array_equal(ol.OracleScene.finalize(acc, spp), r["u8"])
+    acc2 = np.zeros((h, w, 4), np.float32)
+    o.render_accumulate(acc2, w, h, 0, 8, nthreads=8)
+    o.render_accumulate(acc2, w, h, 8, 8, nthreads=8)
+    assert np.max(np.abs(acc2 - acc)) <= 1e-4 * spp

@@ -4,7 +4,7 @@ sys.path.insert(0, "."); sys.path.insert(0, "tests")
 import cuda_ray_tracer_amd as m
 from cuda_ray_tracer_amd import api
 name, w, h, spp = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4])
-stl = m.parseInput(f"scenes/{name}.txt")
+stl = m.syntheticScene(1_000_000, 1_000_000, seed=1234) if name == "synthetic" else m.parseInput(f"scenes/{name}.txt")
 out = []
 for optstr in sys.argv[5:7]:
     raw = m.initRawConfigFromStl(stl, 0)
