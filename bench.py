@@ -3,23 +3,31 @@
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--scene tenthousand] [--width 1920 --height 1080 --spp 16]
 
-One step = one frame of the hot path (trace + resolve, scene and BVH resident in HBM, synthetic-free bundled scene):
+One step = one frame of the hot path (trace + resolve, scene and BVH resident in HBM, the reference's own scene file):
 BASELINE.json's headline workload, `tenthousand.txt` at 1920x1080, 16 samples per pixel.  With N > 1 (launched by
 torch.distributed.run, one process per GPU) the frame is cut into interleaved row stripes, every rank renders its
 stripes with a replicated BVH, and the 8-bit framebuffer is gathered to rank 0 over RCCL and re-interleaved there; the
 total work per frame is fixed ("strong" scaling).  Consecutive frames are kept in flight on alternating streams (two per
-GPU; `--serial` for one): the drain of a frame is a single lane's bounce chain, and the next
-frame's workgroups use the CUs it frees.  Rank 0 prints ONE JSON line.
+GPU; `--serial` for one): the drain of a frame is a single lane's bounce chain, and the next frame's workgroups use the CUs
+it frees.  Rank 0 prints ONE JSON line.
 
 value        = rays of the whole frame / max-over-ranks wall time per frame  (Mrays/s; a ray = one hitNearest call with
                bounce != 0), counted by the kernel's counters variant in an untimed pass.
 roofline     = algorithmic bytes of rank 0's trace-kernel launch (64 B per internal-node visit + 16 B per sphere test
                + 48 B per triangle test + 44 B per material fetch, all counted) / its mean duration from HIP events on
-               the launch stream, against 8 TB/s HBM.
+               the launch stream, against 8 TB/s HBM.  The BVH of the bundled scenes lives in L1/L2, so this is delivered
+               node bandwidth, not DRAM utilisation: `measured_hbm_frac` (PMC traffic / kernel time / peak) and the
+               address-unit figures (`ta_busy`, `l1_requests_per_launch`, `ta_floor_ms`, `frac_of_ta_floor`,
+               `valu_issue_frac`) from the committed rocprofv3 --pmc passes (profiles/*pmc_trace_kernel*.json) say what
+               actually bounds the kernel.
+configs      = (N = 1) the other BASELINE configurations on this GPU, a few frames each: spiral 1080p16, redchair 4K64,
+               the synthetic 1 M spheres + 1 M triangles scene at 4K x 256 spp (whole frame on one GPU) -- ms/frame,
+               Mrays/s, node visits per ray, algorithmic roofline fraction.
 cpu_baseline = the CPU oracle (oracle/, a port of the reference's algorithm) on one host core over a bounded
                sub-sample of the same workload (every `step`-th pixel in x and y), N = 1 only.
 """
 import argparse
+import glob
 import json
 import os
 import sys
@@ -29,24 +37,24 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
+HEADLINE = ("tenthousand", 1920, 1080, 16)
 
 
 def algorithmic_bytes(st):
     return st["internal_visits"] * 64 + st["sphere_tests"] * 16 + st["tri_tests"] * 48 + st["mat_fetches"] * 44
 
 
-def measured_traffic(workload):
-    """HBM bytes per trace-kernel launch from the committed rocprofv3 PMC passes (FETCH_SIZE x2 + WRITE_SIZE, see
-    profiles/*traffic*.json); bench.py cannot run the profiler on itself, so this is the last profiled value or None."""
-    import glob
+def committed_pmc(workload):
+    """The newest committed counter summary for this workload (tools/pmc_profile.py -> profiles/*pmc_trace_kernel*.json);
+    bench.py cannot run the profiler on itself."""
     best = None
-    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*traffic*.json"))):
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_trace_kernel*.json"))):
         try:
             d = json.load(open(f))
         except Exception:
             continue
         if d.get("workload") == workload:
-            best = d.get("hbm_bytes_per_launch")
+            best = (os.path.basename(f), d)
     return best
 
 
@@ -62,7 +70,40 @@ def cpu_baseline(scene_file, width, height, spp, step):
     o.close()
     return {"value": st["rays"] / dt / 1e6, "unit": "Mrays/s", "cores": 1, "kind": "port",
             "sample": f"every {step}th pixel in x and y of the {width}x{height} frame at {spp} spp "
-                      f"({st['samples']} samples, {st['rays']} rays, {dt:.1f} s, full nearest-hit shadow rays as in the reference)"}
+                      f"({st['samples']} samples, {st['rays']} rays, {dt:.1f} s; the reference's own traversal: left-first order, "
+                      f"full nearest-hit shadow rays to every light)"}
+
+
+def time_config(m, api, torch, raw, w, h, spp, steps, label, options=None):
+    """A few serial frames of one more configuration on this GPU (N = 1): counters in an untimed pass, then `steps` timed frames."""
+    old = {}
+    for k, v in (options or {}).items():
+        old[k] = raw.get_option(k)
+        raw.set_option(k, v)
+    img = torch.empty(w * h * 4, dtype=torch.uint8, device="cuda")
+    m.render(img, w, h, spp, raw, params=api.render_params(w, h, spp, counters=True))
+    torch.cuda.synchronize()
+    st = raw.stats()
+    if w * h * max(spp, 1) <= (1 << raw.get_option("slab_log2")):
+        m.render(img, w, h, spp, raw)                  # warm-up: a one-slab frame runs with the chunk order measured on the previous one
+        torch.cuda.synchronize()
+    raw.stats()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        m.render(img, w, h, spp, raw)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    ks = raw.stats()
+    for k, v in old.items():
+        raw.set_option(k, v)
+    del img
+    ab = algorithmic_bytes(st)
+    kms = ks["trace_kernel_ms_mean"]
+    return {"workload": label, "ms_per_frame": dt * 1e3, "trace_kernel_ms": kms, "Mrays_per_s": st["rays"] / dt / 1e6, "rays_per_frame": st["rays"],
+            "node_visits_per_ray": st["internal_visits"] / max(st["rays"], 1),
+            "leaf_tests_per_ray": (st["sphere_tests"] + st["tri_tests"]) / max(st["rays"], 1),
+            "algorithmic_GBps": ab / (kms * 1e-3) / 1e9, "frac": ab / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS, "frames_timed": steps,
+            "options": options or {}}
 
 
 def main():
@@ -70,20 +111,21 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--scene", default="tenthousand")
-    ap.add_argument("--width", type=int, default=1920)
-    ap.add_argument("--height", type=int, default=1080)
-    ap.add_argument("--spp", type=int, default=16)
+    ap.add_argument("--scene", default=HEADLINE[0])
+    ap.add_argument("--width", type=int, default=HEADLINE[1])
+    ap.add_argument("--height", type=int, default=HEADLINE[2])
+    ap.add_argument("--spp", type=int, default=HEADLINE[3])
     ap.add_argument("--stripe-rows", type=int, default=4)
     ap.add_argument("--cpu-step", type=int, default=3, help="sub-sampling step of the CPU baseline (0 = skip)")
     ap.add_argument("--frames-in-flight", type=int, default=0,
-                    help="consecutive frames overlapped on separate streams (1..4; default 2 on one GPU, 4 on several)")
+                    help="consecutive frames overlapped on separate streams (1..4; default 2)")
     ap.add_argument("--serial", action="store_true", help="one frame in flight (no overlap of consecutive frames)")
     ap.add_argument("--share-of", type=int, default=0,
                     help="diagnostic: one process renders only part 0 of an N-way stripe partition (what one rank of N does, without "
                          "the gather); the line then reports that share's rays and time, not a whole job")
     ap.add_argument("--png", default=None, help="write the last frame here (rank 0)")
     ap.add_argument("--headline-only", action="store_true", help="skip the extra configurations (profiling runs)")
+    ap.add_argument("--config5-spp", type=int, default=256, help="samples per pixel of the synthetic 2 M-primitive configuration (BASELINE: 256)")
     args = ap.parse_args()
 
     import torch
@@ -106,12 +148,14 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    backend = None
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if rehearse:
             dist.init_process_group("gloo", rank=rank, world_size=world)
         else:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        backend = dist.get_backend()
 
     scene_file = os.path.join(ROOT, "scenes", args.scene + ".txt")
     W, H, SPP = args.width, args.height, args.spp
@@ -134,15 +178,38 @@ def main():
     parts = [g.new_part_buffer(dev) for g in gatherers]
     part = parts[0]
     frame_no = [0]
+    # per-frame device times of this rank: its part's render and (N > 1) the gather + re-interleave that follows it
+    ev = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(nfl)]
+    render_ms, gather_ms = [], []
+    pending = [None] * nfl
 
-    def step():
+    def collect(i):
+        if pending[i]:
+            e0, e1, e2 = ev[i]
+            e2.synchronize()
+            render_ms.append(e0.elapsed_time(e1))
+            gather_ms.append(e1.elapsed_time(e2))
+            pending[i] = None
+
+    def step(timed=False):
         i = frame_no[0] % nfl
         frame_no[0] += 1
+        if timed:
+            collect(i)
         with torch.cuda.stream(streams[i]):
+            e0, e1, e2 = ev[i]
+            if timed:
+                e0.record()
             m.render(parts[i], W, H, SPP, raw, params=mine)
+            if timed:
+                e1.record()
+            out = parts[i]                                 # N = 1: the part already is the whole row-major frame
             if world > 1:
-                return gatherers[i].gather(parts[i])   # RCCL gather over xGMI (<= 1.04 MB per rank at 1080p) + re-interleave on rank 0
-        return parts[i]                                # N = 1: the part already is the whole row-major frame
+                out = gatherers[i].gather(parts[i])        # RCCL gather over xGMI (<= 1.04 MB per rank at 1080p) + re-interleave on rank 0
+            if timed:
+                e2.record()
+                pending[i] = True
+        return out
 
     # untimed counting pass (same rays every frame: the RNG is keyed by pixel and sample index only)
     cparams = partition.params(prank, SPP, counters=True)
@@ -164,16 +231,25 @@ def main():
     t0 = time.perf_counter()
     raw.stats()                                            # reset the library's running mean of trace-kernel times
     for _ in range(args.steps):
-        step()
+        step(timed=True)
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    for i in range(nfl):
+        collect(i)
     kst = raw.stats()
     tmax = torch.tensor([dt], dtype=torch.float64, device=cdev)
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax.item())
+    # every rank's mean render / gather time (diagnostics of the N > 1 line)
+    mine_ms = torch.tensor([sum(render_ms) / max(len(render_ms), 1), sum(gather_ms) / max(len(gather_ms), 1), kst["trace_kernel_ms_mean"]],
+                           dtype=torch.float64, device=cdev)
+    all_ms = [mine_ms]
+    if world > 1:
+        all_ms = [torch.zeros_like(mine_ms) for _ in range(world)]
+        dist.all_gather(all_ms, mine_ms)
 
     if args.png:                      # one more frame (a collective on several GPUs: every rank takes part)
         fr = step()
@@ -186,8 +262,33 @@ def main():
         mean_kernel_ms = kst["trace_kernel_ms_mean"]        # HIP events around every timed frame's trace kernel, on its launch stream
         my_bytes = algorithmic_bytes(cst)
         achieved = my_bytes / (mean_kernel_ms * 1e-3) / 1e9
+        workload = f"{args.scene}.txt {W}x{H} {SPP}spp"
+        roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                "traffic": None, "kernel": "trace_kernel", "kernel_ms": mean_kernel_ms,
+                "algorithmic_bytes_per_launch": int(my_bytes),
+                "per_ray": {"internal_visits": cst["internal_visits"] / max(cst["rays"], 1),
+                            "sphere_tests": cst["sphere_tests"] / max(cst["rays"], 1),
+                            "tri_tests": cst["tri_tests"] / max(cst["rays"], 1)},
+                "note": "algorithmic bytes are delivered node bandwidth: the bundled scenes' BVH is served from L1/L2, so frac is not DRAM "
+                        "utilisation (measured_hbm_frac is); the kernel is bound by the address units and VALU issue (ta_*, valu_issue_frac)"}
+        pmc = committed_pmc(workload) if world == 1 and pworld == 1 else None
+        if pmc:
+            name, d = pmc
+            dv = d.get("derived", {})
+            roof["traffic"] = d.get("hbm_bytes_per_launch")
+            roof["pmc_source"] = "profiles/" + name
+            roof["pmc_kernel_ms"] = d.get("kernel_ms_under_pmc")
+            if roof["traffic"] and roof["pmc_kernel_ms"]:
+                roof["measured_hbm_frac"] = roof["traffic"] / (roof["pmc_kernel_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS
+            for k_out, k_in in (("ta_busy", "ta_busy"), ("l1_requests_per_launch", "l1_requests"), ("ta_floor_ms", "ta_floor_ms"),
+                                ("l1_hit_rate", "l1_hit_rate"), ("l2_hit_rate", "l2_hit_rate"), ("valu_issue_frac", "valu_issue_frac"),
+                                ("active_lanes_per_valu_inst", "active_lanes"), ("wave_wait_frac", "wave_wait_frac")):
+                if k_in in dv:
+                    roof[k_out] = dv[k_in]
+            if "ta_floor_ms" in dv and roof["pmc_kernel_ms"]:
+                roof["frac_of_ta_floor"] = dv["ta_floor_ms"] / roof["pmc_kernel_ms"]
         out = {
-            "metric": "Mrays/sec, tenthousand.txt 1080p@16spp" if (args.scene, W, H, SPP) == ("tenthousand", 1920, 1080, 16)
+            "metric": "Mrays/sec, tenthousand.txt 1080p@16spp" if (args.scene, W, H, SPP) == HEADLINE
                       else f"Mrays/sec, {args.scene}.txt {W}x{H}@{SPP}spp",
             "value": total_rays * args.steps / dt / 1e6,
             "unit": "Mrays/s",
@@ -198,23 +299,51 @@ def main():
             "vs_baseline": None,
             "dtype": "f32",
             "data": "bundled scene file scenes/%s.txt (the reference's own input); no synthetic substitution" % args.scene,
-            "config": {"workload": f"{args.scene}.txt {W}x{H} {SPP}spp", "rays_per_frame": int(total_rays),
+            "config": {"workload": workload, "rays_per_frame": int(total_rays),
                        "samples_per_frame": int(counts[5].item()), "parallelism": f"image stripes x{world}" if world > 1 else (f"DIAGNOSTIC: part 0 of {pworld} stripe sets on one GPU" if pworld > 1 else "single GPU"), "frames_in_flight": nfl,
-                       "stripe_rows": stripe_rows, "lbvh_build_ms": build_ms},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": measured_traffic(f"{args.scene}.txt {W}x{H} {SPP}spp") if world == 1 else None, "kernel": "trace_kernel", "kernel_ms": mean_kernel_ms,
-                         "algorithmic_bytes_per_launch": int(my_bytes),
-                         "per_ray": {"internal_visits": cst["internal_visits"] / max(cst["rays"], 1),
-                                     "sphere_tests": cst["sphere_tests"] / max(cst["rays"], 1),
-                                     "tri_tests": cst["tri_tests"] / max(cst["rays"], 1)}},
+                       "stripe_rows": stripe_rows, "lbvh_build_ms": build_ms, "traversal": raw.get_option("traversal")},
+            "roofline": roof,
         }
+        if world > 1:
+            out["multi_gpu"] = {"backend": backend, "rccl_ranks": dist.get_world_size(),
+                                "per_rank_render_ms": [float(t[0]) for t in all_ms], "per_rank_gather_ms": [float(t[1]) for t in all_ms],
+                                "per_rank_trace_kernel_ms": [float(t[2]) for t in all_ms],
+                                "note": "render = this rank's part (device time on its stream); gather = from the end of its render to the end of "
+                                        "the framebuffer gather (+ re-interleave on rank 0), i.e. it includes waiting for the slowest rank"}
+        if world == 1 and pworld == 1 and not args.headline_only and (args.scene, W, H, SPP) == HEADLINE:
+            # the other BASELINE configurations on this GPU (a few frames each, serial)
+            extra = []
+            raw.close()
+            raw = None
+            for scene, w, h, spp, steps in (("spiral", 1920, 1080, 16, 5), ("redchair", 3840, 2160, 64, 2)):
+                s2 = m.parseInput(os.path.join(ROOT, "scenes", scene + ".txt"))
+                r2 = m.initRawConfigFromStl(s2, local_rank)
+                m.build_lbvh_karas(r2)
+                extra.append(time_config(m, api, torch, r2, w, h, spp, steps, f"{scene}.txt {w}x{h} {spp}spp"))
+                r2.close()
+            s5 = m.syntheticScene(1_000_000, 1_000_000, seed=1234)
+            r5 = m.initRawConfigFromStl(s5, local_rank)
+            b5 = m.build_lbvh_karas(r5)
+            lab = f"synthetic 1M spheres + 1M triangles 3840x2160 {args.config5_spp}spp (whole frame on this GPU)"
+            c5 = time_config(m, api, torch, r5, 3840, 2160, args.config5_spp, 1, lab)
+            c5["lbvh_build_ms"] = b5
+            c5["note"] = "default traversal: near-child-first only where both subtrees hold spheres only -- bit-identical to the reference's order by construction"
+            extra.append(c5)
+            c5b = time_config(m, api, torch, r5, 3840, 2160, args.config5_spp, 1, lab, options={"traversal": 2})
+            c5b["lbvh_build_ms"] = b5
+            c5b["note"] = ("option traversal = 2: near-child-first at every node; identical bytes on this scene (tests/test_gpu_parity.py), but a "
+                           "triangle-silhouette sample may differ where the reference's own result depends on its visiting order")
+            extra.append(c5b)
+            r5.close()
+            out["configs"] = extra
         if world == 1 and args.cpu_step > 0:
             out["cpu_baseline"] = cpu_baseline(scene_file, W, H, SPP, args.cpu_step)
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out), flush=True)
 
-    raw.close()
+    if raw is not None:
+        raw.close()
     if world > 1:
         dist.destroy_process_group()
 

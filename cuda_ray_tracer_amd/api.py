@@ -67,6 +67,14 @@ class Stats(C.Structure):
         return {n: getattr(self, n) for n, _ in self._fields_}
 
 
+MULTI_MAX_GPUS = 16
+
+
+class MultiStats(C.Structure):
+    _fields_ = [("num_gpus", C.c_int32), ("build_ms", C.c_float), ("render_ms", C.c_float * MULTI_MAX_GPUS),
+                ("gather_ms", C.c_float), ("frame_ms", C.c_float)]
+
+
 class TreeNode(C.Structure):
     _fields_ = [("xmin", C.c_float), ("xmax", C.c_float), ("ymin", C.c_float), ("ymax", C.c_float),
                 ("zmin", C.c_float), ("zmax", C.c_float),
@@ -78,6 +86,7 @@ EXPORTS = [
     "mirt_host_scene_destroy", "mirt_host_scene_desc", "mirt_host_scene_filename", "mirt_scene_create",
     "mirt_scene_destroy", "mirt_scene_set_option", "mirt_scene_get_option", "mirt_build_lbvh", "mirt_render_num_pixels", "mirt_render", "mirt_render_accumulate", "mirt_finalize", "mirt_scatter_part",
     "mirt_get_stats", "mirt_get_tree", "mirt_probe_math", "mirt_probe_xorwow", "mirt_write_png",
+    "mirt_multi_create", "mirt_multi_destroy", "mirt_multi_num_parts", "mirt_multi_set_option", "mirt_render_frame_multi",
 ]
 
 _lib = None
@@ -122,6 +131,12 @@ def lib():
     L.mirt_probe_math.argtypes = [C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
     L.mirt_probe_xorwow.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
     L.mirt_write_png.argtypes = [C.c_char_p, C.c_void_p, C.c_int, C.c_int]
+    L.mirt_multi_create.argtypes = [C.POINTER(SceneDesc), C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_void_p)]
+    L.mirt_multi_destroy.argtypes = [C.c_void_p]
+    L.mirt_multi_destroy.restype = None
+    L.mirt_multi_num_parts.argtypes = [C.c_void_p]
+    L.mirt_multi_set_option.argtypes = [C.c_void_p, C.c_char_p, C.c_int]
+    L.mirt_render_frame_multi.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.POINTER(MultiStats)]
     _lib = L
     return L
 
@@ -259,6 +274,36 @@ copyConfigDataToDevice = initRawConfigFromStl
 
 def freeRawConfigDeviceMemory(raw):
     raw.close()
+
+
+class MultiGpu:
+    """mirt_multi_*: one process, several GPUs, RCCL framebuffer gather (include/mirt.h)."""
+
+    def __init__(self, stl, ngpu=1, devices=None):
+        self._keep = stl
+        dv = (C.c_int * ngpu)(*devices) if devices is not None else None
+        h = C.c_void_p()
+        _check(lib().mirt_multi_create(C.byref(stl.desc), ngpu, dv, C.byref(h)))
+        self._h = h
+
+    def render_frame(self, width, height, spp, stripe_rows=4):
+        import numpy as np
+        out = np.zeros((height, width, 4), np.uint8)
+        st = MultiStats()
+        _check(lib().mirt_render_frame_multi(self._h, width, height, spp, stripe_rows, out.ctypes.data, C.byref(st)))
+        n = st.num_gpus
+        return out, dict(num_gpus=n, build_ms=st.build_ms, render_ms=list(st.render_ms)[:n], gather_ms=st.gather_ms, frame_ms=st.frame_ms)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().mirt_multi_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 def _stream_ptr(stream):

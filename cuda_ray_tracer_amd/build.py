@@ -17,7 +17,7 @@ LIB = os.path.join(OUT, "libmirt.so")
 CLI = os.path.join(OUT, "raytracer")
 ARCH = "gfx950"
 
-LIB_SOURCES = ["host_scene.cpp", "png_writer.cpp", "xorwow_tables.cpp", "lbvh_build.hip", "render.hip", "wavefront.hip", "api.hip"]
+LIB_SOURCES = ["host_scene.cpp", "png_writer.cpp", "xorwow_tables.cpp", "multi.cpp", "lbvh_build.hip", "render.hip", "wavefront.hip", "api.hip"]
 COMMON = ["-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math", "-Wall", "-Wno-unused-function", "-Wno-unused-value", "-Wno-unused-result",
           f"--offload-arch={ARCH}", "-fno-gpu-flush-denormals-to-zero"]
 
@@ -61,7 +61,7 @@ def build(force=False, verbose=False):
                 print(" ".join(cmd), flush=True)
             subprocess.check_call(cmd)
     if force or _stale(LIB, objs):
-        cmd = [hipcc, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", LIB] + objs + ["-lz"]
+        cmd = [hipcc, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", LIB] + objs + ["-lz", "-ldl"]
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.check_call(cmd)

@@ -1,11 +1,12 @@
 // raytracer -- the reference's command line (main.cu:25-94) over libmirt's C ABI:
 //
-//     raytracer scene.txt [--width W] [--height H] [--spp N] [--out file.png] [--device D]
+//     raytracer scene.txt [--width W] [--height H] [--spp N] [--out file.png] [--device D] [--gpus N] [--traversal 0|1|2]
 //
 // Same contract: one positional scene file, the PNG is named by the scene's `png W H name` line and written to the
 // current directory, the same phase timing lines go to stdout, and the reference's error messages + exit codes are
 // kept ("Error opening file...", "One of the lines are not valid.": exit 1; device errors: EXIT_FAILURE).
-// The optional flags override resolution / samples per pixel of the scene file (BASELINE.json's configs do).
+// The optional flags override resolution / samples per pixel of the scene file (BASELINE.json's configs do).  --gpus N
+// renders the frame on N GPUs of this node (image stripes, replicated BVH, RCCL framebuffer gather: mirt_multi_*).
 #include <hip/hip_runtime.h>
 
 #include <chrono>
@@ -30,7 +31,7 @@ static void die_on(int rc, const char* what)
 int main(int argc, char* argv[])
 {
   if (argc < 2) { std::cout << "Error opening file..." << std::endl; return 1; }
-  int ow = 0, oh = 0, ospp = -1, device = 0;
+  int ow = 0, oh = 0, ospp = -1, device = 0, gpus = 1, traversal = -1;
   std::string out_override;
   for (int i = 2; i < argc; ++i) {
     std::string a = argv[i];
@@ -40,6 +41,8 @@ int main(int argc, char* argv[])
     else if (a == "--spp") { need(1); ospp = atoi(argv[++i]); }
     else if (a == "--out") { need(1); out_override = argv[++i]; }
     else if (a == "--device") { need(1); device = atoi(argv[++i]); }
+    else if (a == "--gpus") { need(1); gpus = atoi(argv[++i]); }
+    else if (a == "--traversal") { need(1); traversal = atoi(argv[++i]); }
     else { std::cerr << "unknown option " << a << std::endl; return 2; }
   }
 
@@ -50,9 +53,40 @@ int main(int argc, char* argv[])
   const int width = ow > 0 ? ow : desc.width, height = oh > 0 ? oh : desc.height;
   const int spp = ospp >= 0 ? ospp : desc.aa;
 
+  if (gpus > 1) {
+    // several GPUs: the same phases, each over all devices
+    auto start = std::chrono::high_resolution_clock::now();
+    MirtMulti* mm = nullptr;
+    die_on(mirt_multi_create(&desc, gpus, nullptr, &mm), "copyConfigDataToDevice");
+    if (traversal >= 0) die_on(mirt_multi_set_option(mm, "traversal", traversal), "mirt_multi_set_option");
+    auto end = std::chrono::high_resolution_clock::now();
+    std::chrono::duration<double> elapsed = end - start;
+    std::cout << "Initialize raw config time: " << elapsed.count() << " seconds" << std::endl;
+    std::vector<uint8_t> img((size_t)width * height * 4);
+    MirtMultiStats st;
+    start = std::chrono::high_resolution_clock::now();
+    die_on(mirt_render_frame_multi(mm, width, height, spp, 4, img.data(), &st), "render");
+    end = std::chrono::high_resolution_clock::now();
+    elapsed = end - start;
+    if (desc.num_prims > 0) {
+      printf("LBVH Build time (N=%d): %.3f ms\n", desc.num_prims, st.build_ms);
+      printf("LBVH Build (Karas algorithm) complete. Total nodes: %u\n", 2u * (unsigned)desc.num_prims - 1u);
+    }
+    std::cout << "Render time: " << elapsed.count() << " seconds" << std::endl;
+    printf("GPUs: %d, framebuffer gather: %.3f ms, per-GPU render ms:", st.num_gpus, st.gather_ms);
+    for (int r = 0; r < st.num_gpus && r < MIRT_MULTI_MAX_GPUS; ++r) printf(" %.3f", st.render_ms[r]);
+    printf("\n");
+    const std::string out = out_override.empty() ? std::string(mirt_host_scene_filename(hs)) : out_override;
+    die_on(mirt_write_png(out.c_str(), img.data(), width, height), "Image::save");
+    mirt_multi_destroy(mm);
+    mirt_host_scene_destroy(hs);
+    return 0;
+  }
+
   auto start = std::chrono::high_resolution_clock::now();
   MirtScene* sc = nullptr;
   die_on(mirt_scene_create(&desc, device, &sc), "copyConfigDataToDevice");
+  if (traversal >= 0) die_on(mirt_scene_set_option(sc, "traversal", traversal), "mirt_scene_set_option");
   auto end = std::chrono::high_resolution_clock::now();
   std::chrono::duration<double> elapsed = end - start;
   std::cout << "Initialize raw config time: " << elapsed.count() << " seconds" << std::endl;
@@ -80,6 +114,10 @@ int main(int argc, char* argv[])
   start = std::chrono::high_resolution_clock::now();
   die_on(mirt_render(sc, &p, d_image, nullptr, nullptr), "render");
   HIP_CHECK(hipDeviceSynchronize());
+  {
+    MirtStats st;      // (a capacity overflow during the render is an error, not a warning on stdout as bvh_traversal.cu:154-164)
+    die_on(mirt_get_stats(sc, &st), "render");
+  }
   end = std::chrono::high_resolution_clock::now();
   elapsed = end - start;
   std::cout << "Render time: " << elapsed.count() << " seconds" << std::endl;

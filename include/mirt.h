@@ -153,6 +153,29 @@ int mirt_finalize(const MirtRenderParams* p, const void* d_accum_f32, int total_
 /* Scatter a compact part buffer back into a full row-major frame (device to device). */
 int mirt_scatter_part(const MirtRenderParams* p, const void* d_part_rgba8, void* d_frame_rgba8, void* stream);
 
+/* ---- several GPUs in one process --------------------------------------------------------------- */
+/* Not in the reference (single GPU, main.cu:25-94).  The scene is uploaded to every listed device and every device builds
+ * the identical LBVH; a frame is cut into interleaved stripes of `stripe_rows` rows, device r renders part r (a
+ * MirtRenderParams with num_parts = ngpu, part = r), the parts are gathered to the first device with one grouped RCCL
+ * send/recv exchange over xGMI and re-interleaved there.  Any partition gives the bytes of the single-GPU frame (samples are
+ * seeded by global pixel and sample index, draw.cu:162).  RCCL is loaded at run time, and only for ngpu > 1. */
+#define MIRT_MULTI_MAX_GPUS 16
+typedef struct MirtMulti MirtMulti;
+typedef struct MirtMultiStats {
+  int32_t num_gpus;
+  float build_ms;                          /* slowest device's LBVH build */
+  float render_ms[MIRT_MULTI_MAX_GPUS];    /* device time of each part's render (HIP events on its stream) */
+  float gather_ms;                         /* end of device 0's render -> frame re-interleaved on device 0 (includes waiting for the slowest peer) */
+  float frame_ms;                          /* host wall clock of the call, host copy included */
+} MirtMultiStats;
+/* devices: ngpu device indices, or NULL for 0..ngpu-1.  Uploads and builds synchronously. */
+int mirt_multi_create(const MirtSceneDesc* desc, int ngpu, const int* devices, MirtMulti** out);
+void mirt_multi_destroy(MirtMulti* mm);
+int mirt_multi_num_parts(const MirtMulti* mm);
+int mirt_multi_set_option(MirtMulti* mm, const char* name, int value);      /* mirt_scene_set_option on every device's scene */
+/* Renders one width x height frame at spp samples per pixel; host_rgba (nullable) receives width*height*4 bytes.  Synchronous. */
+int mirt_render_frame_multi(MirtMulti* mm, int width, int height, int spp, int stripe_rows, uint8_t* host_rgba, MirtMultiStats* stats);
+
 typedef struct MirtStats {
   /* filled by a render with MIRT_RENDER_COUNTERS */
   uint64_t samples, rays, shadow_rays, internal_visits, sphere_tests, tri_tests, mat_fetches, max_stack;

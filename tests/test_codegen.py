@@ -22,3 +22,54 @@ def test_no_scratch_reloads_on_the_traversal_loop_hot_path():
     # at most one single-register reload (today: an LDS address of the shade phase restored after the triangle test used
     # its register); the expensive cases were two of them, on the push and on the pop
     assert len([t for t in scratch if not t.startswith("scratch_load_dwordx2")]) <= 1, (cnt, scratch)
+
+
+def _kernel_instructions(src, kernel):
+    """Compiles csrc/<src> to gfx950 assembly (no GPU needed) and returns the instructions of `kernel`."""
+    import re
+    import subprocess
+    import tempfile
+    from cuda_ray_tracer_amd import build as B
+    out = os.path.join(tempfile.gettempdir(), "mirt_codegen_" + src + ".s")
+    cmd = [B._hipcc()] + [c for c in B.COMMON if c != "-fPIC"] + ["-x", "hip", "-S", "--cuda-device-only", os.path.join(B.CSRC, src), "-o", out]
+    subprocess.run(cmd, check=True, capture_output=True)
+    body, inside = [], False
+    for l in open(out).read().splitlines():
+        if re.match(r"^_ZN4mirt.*" + kernel + r".*:", l):
+            inside = True
+            continue
+        if inside and "s_endpgm" in l:
+            break
+        if inside:
+            t = l.split(";")[0].strip()
+            if t and not t.startswith("."):
+                body.append(t)
+    assert body, kernel
+    return body
+
+
+def test_refit_hand_off_keeps_its_write_through_stores_and_bypassing_loads():
+    """refit_pack_kernel hands boxes from the first thread at a node to the second without cache-wide fences: every box word
+    is stored write-through (sc1), the stores are drained (s_waitcnt vmcnt(0)) before the arrival counter is bumped, and the
+    sibling's box is read with L1-bypassing (sc1) loads.  The reference has a plain race there (lbvh_builder.cu:343-359,381).
+    The source expresses this with relaxed agent-scope atomics + an inline s_waitcnt; this test pins what the compiler makes
+    of it, so that a toolchain update cannot silently bring the race back."""
+    ins = _kernel_instructions("lbvh_build.hip", "refit_pack_kernel")
+    dword_stores = [t for t in ins if t.startswith("global_store_dword ")]
+    assert len(dword_stores) >= 12 and all(t.endswith(" sc1") or " sc1" in t for t in dword_stores), dword_stores   # leaf box + merged box
+    sc1_loads = [t for t in ins if t.startswith("global_load_dword ") and " sc1" in t]
+    assert len(sc1_loads) >= 12, sc1_loads                                                                          # both children's boxes
+    atomics = [i for i, t in enumerate(ins) if t.startswith("global_atomic_add")]
+    assert atomics
+    for i in atomics:
+        # walking back from the counter add, the first memory-related instruction must be the drain
+        drained = False
+        for t in reversed(ins[:i]):
+            if t.startswith("s_waitcnt") and "vmcnt(0)" in t:
+                drained = True
+                break
+            if t.startswith(("global_", "flat_", "buffer_", "scratch_")):
+                break
+        assert drained, ins[max(0, i - 8):i + 1]
+    # no wider box stores sneaked in without the bit (the dwordx4 stores are the node record, which is only read by later kernels)
+    assert not [t for t in ins if t.startswith(("global_store_dwordx2", "global_store_dwordx3"))]

@@ -27,5 +27,5 @@ for src in B.LIB_SOURCES:
         obj = os.path.join(B.OUT, base)
     objs.append(obj)
 lib = os.path.join(out, "libmirt.so")
-subprocess.check_call([B._hipcc(), "-shared", "-fPIC", f"--offload-arch={B.ARCH}", "-o", lib] + objs + ["-lz"])
+subprocess.check_call([B._hipcc(), "-shared", "-fPIC", f"--offload-arch={B.ARCH}", "-o", lib] + objs + ["-lz", "-ldl"])
 print(lib)

@@ -5,12 +5,12 @@
     python3 tools/pmc_profile.py OUT_JSON [--scene tenthousand] [--tag r02] [--env KEY=VAL ...] [--groups a,b,...]
 
 Run on the GPU box (gpurun); copy the JSON into profiles/.  Derived figures:
-  ta_busy            TA_TA_BUSY_sum / (256 address units x GRBM_GUI_ACTIVE)
+  ta_busy            TA_TA_BUSY_sum / (256 address units x launch cycles); launch cycles = GRBM_GUI_ACTIVE / 8 (summed over the XCDs)
   l1_requests        TCP_TOTAL_CACHE_ACCESSES_sum per launch (one per active lane per vector-memory instruction)
   ta_floor_ms        l1_requests / (256 CUs x 2.4 GHz): the address units retire about one lane request per cycle per CU
   l1_hit_rate        1 - TCP_TCC_READ_REQ_sum / TCP_TOTAL_CACHE_ACCESSES_sum
   l2_hit_rate        TCC_HIT_sum / (TCC_HIT_sum + TCC_MISS_sum)
-  valu_issue_frac    SQ_ACTIVE_INST_VALU x 4 / (1024 SIMDs x GRBM_GUI_ACTIVE)   (SQ_ACTIVE_INST_* count quad-cycles)
+  valu_issue_frac    SQ_INSTS_VALU x 4 issue cycles / (1024 SIMDs x launch cycles)
   active_lanes       SQ_THREAD_CYCLES_VALU / (SQ_ACTIVE_INST_VALU x 64)
   hbm_bytes          2 x FETCH_SIZE + WRITE_SIZE (KB -> B; gfx950 tallies 128-B read requests as 64 B, MI355X_MICROARCH.md)
 """
@@ -35,6 +35,7 @@ GROUPS = {
 }
 CLOCK_HZ = 2.4e9
 CUS = 256
+XCDS = 8          # GRBM_GUI_ACTIVE is summed over the eight XCDs: cycles of the launch = sum / 8
 
 
 def main():
@@ -95,6 +96,8 @@ def main():
            "env": args.env, "per_launch": raw, "launches_averaged": launches, "kernel_ms_under_pmc": kernel_ms, "derived": {}}
     dv = out["derived"]
     g = raw.get("GRBM_GUI_ACTIVE")
+    if g:
+        g = g / XCDS
     if g and "TA_TA_BUSY_sum" in raw:
         dv["ta_busy"] = raw["TA_TA_BUSY_sum"] / (CUS * g)
         dv["gui_active_ms"] = g / CLOCK_HZ * 1e3
