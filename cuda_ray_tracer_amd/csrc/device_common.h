@@ -235,16 +235,23 @@ MIRT_DEV void xw_apply_tables(const RngTablesDev& t, uint32_t m, const uint32_t*
       const uint4 q = t.A[e];
       a0 ^= q.x; a1 ^= q.y; a2 ^= q.z; a3 ^= q.w;
       a4 ^= t.B[e];
+      // the 4-bit tables take 24 (40) lookups: issued all at once the loaded values do not fit the registers the shade phase
+      // has, and the compiler spilled each of them to scratch behind its own wait -- six lookups in flight at a time instead
+      if (BITS == 4 && ((iw * PER_WORD + c) % 6) == 5) asm volatile("" ::: "memory");      // (six: 128 spp 354 -> 286 ms; four: 295 ms)
     }
   }
   out[0] = a0; out[1] = a1; out[2] = a2; out[3] = a3; out[4] = a4;
 }
 
 // curand_init(1234 + pixel, sample, 0) for spp > 1 (draw.cu:162) / curand_init(1234, pixel, 0) for spp <= 1 (draw.cu:105)
+// TABLES: 0 = whatever the tables are (run-time branches); 8 = per-sample tables with 8-bit chunks only (spp 2..64); 4 = the
+// 4-bit forms only (per-sample tables of spp > 64, and the per-pixel tables of spp <= 1).  The trace kernel is instantiated
+// per form: it runs at the register edge, and the code of the form it does not use moved its allocation by a per cent or two.
+template <int TABLES = 0>
 MIRT_DEV void xw_init(Xorwow& s, const RngTablesDev& t, uint32_t pixel, uint32_t sample)
 {
   uint32_t out[5];
-  if (t.mode == 0) {
+  if (TABLES == 8 || (TABLES != 4 && t.mode == 0) || (TABLES == 4 && t.mode == 0)) {
     const uint32_t seed_lo = 1234u + pixel;
     const uint32_t s0 = seed_lo ^ 0xaad26b49u;
     const uint32_t s1 = 0u ^ 0xf7dcefddu;
@@ -252,7 +259,7 @@ MIRT_DEV void xw_init(Xorwow& s, const RngTablesDev& t, uint32_t pixel, uint32_t
     const uint32_t t1 = 2591861531u * s1;
     s.d = 6615241u + t1 + t0;
     uint32_t in[3] = {123456789u + t0, 362436069u ^ t0, 5783321u + t0};
-    if (t.chunk_bits == 8) xw_apply_tables<3, 8>(t, sample, in, out);
+    if (TABLES == 8 || (TABLES == 0 && t.chunk_bits == 8)) xw_apply_tables<3, 8>(t, sample, in, out);
     else xw_apply_tables<3, 4>(t, sample, in, out);
   } else {
     const uint32_t blk = pixel >> 8;

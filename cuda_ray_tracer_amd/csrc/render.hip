@@ -52,7 +52,7 @@ constexpr int MAX_CHUNK_SHIFT = 8, MIN_CHUNK_SHIFT = 6;   // a wave takes 64..25
 #define MIRT_STACK_LDS 32
 #endif
 constexpr int STACK_LDS = MIRT_STACK_LDS;
-template <bool COUNT, bool PROF>
+template <bool COUNT, bool PROF, int TABLES>
 __global__ void __launch_bounds__(TRACE_BLOCK, MIRT_WAVES_PER_SIMD) trace_kernel(const RenderArgs* __restrict__ ap, const HotArgs h)
 {
   // PROF: diagnostic build only -- cycle stamps per phase, written to h.prof (never used for timing claims)
@@ -147,7 +147,7 @@ __global__ void __launch_bounds__(TRACE_BLOCK, MIRT_WAVES_PER_SIMD) trace_kernel
           given += take;
         }
         const unsigned long long pf_i0 = PROF ? clock64() : 0;
-        if (my >= 0) init_sample<COUNT>(a, S, cn, my);
+        if (my >= 0) init_sample<COUNT, TABLES>(a, S, cn, my);
         if (PROF) pf_init += clock64() - pf_i0;
       }
     }
@@ -544,7 +544,7 @@ static int grid_blocks(int device)
   hipDeviceProp_t prop;
   if (hipGetDeviceProperties(&prop, device) != hipSuccess) return 1024;
   int per_cu = 0;
-  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, trace_kernel<false, false>, TRACE_BLOCK, 0) != hipSuccess || per_cu < 1) per_cu = 4 * 256 / TRACE_BLOCK;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, trace_kernel<false, false, 8>, TRACE_BLOCK, 0) != hipSuccess || per_cu < 1) per_cu = 4 * 256 / TRACE_BLOCK;
   return prop.multiProcessorCount * per_cu;
 }
 
@@ -786,13 +786,19 @@ static int render_impl(MirtScene* sc, const MirtRenderParams* p, void* d_rgba8, 
       MIRT_HIP(hipMemcpyAsync(adev, &a, sizeof(RenderArgs), hipMemcpyHostToDevice, stream));
 #if MIRT_DIAG_PROF
       if (prof) {
-        hipLaunchKernelGGL((trace_kernel<false, true>), dim3(blocks), dim3(TRACE_BLOCK), 0, stream, adev, h);
+        hipLaunchKernelGGL((trace_kernel<false, true, 0>), dim3(blocks), dim3(TRACE_BLOCK), 0, stream, adev, h);
         int rc = report_prof(cx, blocks, stream);
         if (rc != MIRT_OK) return rc;
       } else
 #endif
-      if (count) hipLaunchKernelGGL((trace_kernel<true, false>), dim3(blocks), dim3(TRACE_BLOCK), 0, stream, adev, h);
-      else hipLaunchKernelGGL((trace_kernel<false, false>), dim3(blocks), dim3(TRACE_BLOCK), 0, stream, adev, h);
+      // one instantiation per form of the random-number tables (device_common.h, xw_init)
+      {
+        const bool t8 = a.needs_rng && a.rng.mode == 0 && a.rng.chunk_bits == 8;
+        if (count) { if (t8) hipLaunchKernelGGL((trace_kernel<true, false, 8>), dim3(blocks), dim3(TRACE_BLOCK), 0, stream, adev, h);
+                     else hipLaunchKernelGGL((trace_kernel<true, false, 4>), dim3(blocks), dim3(TRACE_BLOCK), 0, stream, adev, h); }
+        else { if (t8) hipLaunchKernelGGL((trace_kernel<false, false, 8>), dim3(blocks), dim3(TRACE_BLOCK), 0, stream, adev, h);
+               else hipLaunchKernelGGL((trace_kernel<false, false, 4>), dim3(blocks), dim3(TRACE_BLOCK), 0, stream, adev, h); }
+      }
     }
     MIRT_HIP(hipGetLastError());
     if (slab == nslabs - 1) MIRT_HIP(hipEventRecord(cx.ev2, stream));

@@ -546,7 +546,7 @@ MIRT_DEV void advance(const RenderArgs& a, Lane& S, Counters& cn, const long lon
 }
 
 // Start sample `idx` on this lane: pixel, RNG stream, jitter, primary ray (draw.cu:105-123 / 162-171).
-template <bool COUNT>
+template <bool COUNT, int TABLES = 0>
 MIRT_DEV void init_sample_core(const RenderArgs& a, Lane& S, Counters& cn, const long long idx)
 {
   // sample of this launch -> local pixel of the part -> frame pixel, in 32-bit arithmetic (a launch has < 2^31 samples, a
@@ -573,7 +573,7 @@ MIRT_DEV void init_sample_core(const RenderArgs& a, Lane& S, Counters& cn, const
   S.limit = INFINITY;
   S.shadow = false;
   S.batch_pending = false;
-  if (a.needs_rng) xw_init(S.rng, a.rng, pixel, a.seed_per_pixel ? (uint32_t)sidx : 0u);
+  if (a.needs_rng) xw_init<TABLES>(S.rng, a.rng, pixel, a.seed_per_pixel ? (uint32_t)sidx : 0u);
   float fx = (float)px, fy = (float)py;
   if (a.spp >= 1) {
     const float jx = randD(-0.5f, 0.5f, S.rng);
@@ -584,10 +584,10 @@ MIRT_DEV void init_sample_core(const RenderArgs& a, Lane& S, Counters& cn, const
   if (COUNT) cn.samples++;
 }
 
-template <bool COUNT>
+template <bool COUNT, int TABLES = 0>
 MIRT_DEV void init_sample(const RenderArgs& a, Lane& S, Counters& cn, const long long idx)
 {
-  init_sample_core<COUNT>(a, S, cn, idx);
+  init_sample_core<COUNT, TABLES>(a, S, cn, idx);
   if (S.bounce == 0) {   // hitNearest: a ray with bounce 0 never hits (draw.cu:294)
     a.samples[idx] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     S.g = -1;

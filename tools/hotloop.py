@@ -31,12 +31,12 @@ def analyze(defines=()):
     res, want = [], False
     for line in r.stderr.splitlines():
         if "Function Name" in line:
-            want = "trace_kernelILb0ELb0" in line
+            want = "trace_kernelILb0ELb0ELi8E" in line
         elif want and re.search(r"VGPRs:|SGPRs:|Spill|ScratchSize|Occupancy", line):
             res.append(line.split("remark:")[1].rsplit("[-Rpass", 1)[0].strip())
     body, inside = [], False
     for l in open(out).read().splitlines():
-        if re.match(r"^_ZN4mirt.*trace_kernelILb0ELb0.*:", l):
+        if re.match(r"^_ZN4mirt.*trace_kernelILb0ELb0ELi8E.*:", l):
             inside = True
             continue
         if inside and "s_endpgm" in l:

@@ -4,7 +4,7 @@ import cuda_ray_tracer_amd as m
 from cuda_ray_tracer_amd import api
 scenes = sys.argv[1:] or ["tenthousand"]
 for name in scenes:
-    w, h, spp = 1920, 1080, 16
+    w, h, spp = 1920, 1080, int(os.environ.get("PERF_SPP", "16"))
     stl = m.parseInput(f"scenes/{name}.txt")
     raw = m.initRawConfigFromStl(stl, 0)
     m.build_lbvh_karas(raw)
