@@ -31,6 +31,7 @@ class options:
             m.build_lbvh_karas(self.raw)
 
 TOL = 1e-4   # north_star: output pixels within 1e-4 per channel (linear float RGBA before quantisation)
+COUNTER_KEYS = ("samples", "rays", "shadow_rays", "internal_visits", "sphere_tests", "tri_tests", "mat_fetches", "max_stack")
 
 
 def gpu_render(raw, w, h, spp, stripe_rows=None, num_parts=1, part=0, counters=False):
@@ -174,6 +175,39 @@ def test_config5_two_million_primitives_4k_256spp_stripe_matches_oracle():
     o.close()
 
 
+def test_config5_ordered_everywhere_gives_the_same_bytes_on_this_scene():
+    """Option traversal = 2 (near child first at every node, not only between sphere-only subtrees) is NOT exact in general:
+    where a triangle is hit in the reference's 0.001 slack outside its box the reference's own result depends on its visiting
+    order (redchair.txt: 0.1 % of the pixels change).  On BASELINE config 5's scene (random, unconnected triangles) it is:
+    three rows of the 3840x2160 x 256 spp frame give identical bytes, float image included, with 57 % fewer node visits --
+    and its counters equal the oracle's mirror (ORC_FLAG_ORDERED_ALL)."""
+    stl = m.syntheticScene(1_000_000, 1_000_000, seed=1234)
+    raw = m.initRawConfigFromStl(stl, 0)
+    m.build_lbvh_karas(raw)
+    w, h, spp, rows = 3840, 2160, 256, 1
+    parts, part = h // 3, 401                      # part k owns rows k, k + 720, k + 1440
+    raw.set_option("traversal", 0)
+    a8, af = gpu_render(raw, w, h, spp, stripe_rows=rows, num_parts=parts, part=part, counters=True)
+    sa = raw.stats()
+    raw.set_option("traversal", 2)
+    b8, bf = gpu_render(raw, w, h, spp, stripe_rows=rows, num_parts=parts, part=part, counters=True)
+    sb = raw.stats()
+    assert np.array_equal(a8, b8) and np.array_equal(af.view(np.uint32), bf.view(np.uint32))
+    assert sa["rays"] == sb["rays"] and sb["internal_visits"] < 0.5 * sa["internal_visits"]
+    o = ol.OracleScene(ol.ArrayScene(stl), bounds_mode=0)
+    ref = o.render(w, h, spp, tile=(0, part, w, rows), flags=ol.PRODUCT_ALWAYS | ol.FLAG_ORDERED_ALL, nthreads=8)
+    n = w * rows
+    check_image(b8[:n], bf[:n], ref)
+    rawc = m.initRawConfigFromStl(stl, 0)          # counters of the first row alone, against the oracle
+    m.build_lbvh_karas(rawc)
+    rawc.set_option("traversal", 2)
+    c8, cf = gpu_render(rawc, w, h, spp, stripe_rows=rows, num_parts=h, part=part, counters=True)
+    sc = rawc.stats()
+    for k in COUNTER_KEYS:
+        assert sc[k] == ref["stats"][k], (k, sc[k], ref["stats"][k])
+    raw.close(); rawc.close(); o.close()
+
+
 def test_stripe_partition_is_bit_identical_to_whole_frame(gpu_scenes):
     """Tile-split invariance: any partition gives the same bytes."""
     stl, raw = gpu_scenes("tenthousand")
@@ -237,9 +271,6 @@ def test_both_paths_give_identical_bytes(gpu_scenes):
     with options(raw, wavefront=1):
         b8, bf = gpu_render(raw, 200, 120, 16)
     assert np.array_equal(a8, b8) and np.array_equal(af.view(np.uint32), bf.view(np.uint32))
-
-
-COUNTER_KEYS = ("samples", "rays", "shadow_rays", "internal_visits", "sphere_tests", "tri_tests", "mat_fetches", "max_stack")
 
 
 @pytest.mark.parametrize("name,w,h,spp", [("tenthousand", 96, 54, 16), ("spiral", 96, 54, 4), ("redchair", 64, 36, 32), ("tri", 128, 128, 0)])
