@@ -244,8 +244,8 @@ MIRT_DEV void xw_apply_tables(const RngTablesDev& t, uint32_t m, const uint32_t*
 }
 
 // curand_init(1234 + pixel, sample, 0) for spp > 1 (draw.cu:162) / curand_init(1234, pixel, 0) for spp <= 1 (draw.cu:105)
-// TABLES: 0 = whatever the tables are (run-time branches); 8 = per-sample tables with 8-bit chunks only (spp 2..64); 4 = the
-// 4-bit forms only (per-sample tables of spp > 64, and the per-pixel tables of spp <= 1).  The trace kernel is instantiated
+// TABLES: 0 = whatever the tables are (run-time branches); 8 = per-sample tables with 8-bit chunks only (spp 2..16); 4 = the
+// 4-bit forms only (per-sample tables of spp > 16, and the per-pixel tables of spp <= 1).  The trace kernel is instantiated
 // per form: it runs at the register edge, and the code of the form it does not use moved its allocation by a per cent or two.
 template <int TABLES = 0>
 MIRT_DEV void xw_init(Xorwow& s, const RngTablesDev& t, uint32_t pixel, uint32_t sample)

@@ -20,7 +20,7 @@ os.makedirs(out, exist_ok=True)
 objs = []
 for src in B.LIB_SOURCES:
     base = os.path.splitext(src)[0] + ".o"
-    if src.endswith(".hip") and src != "api.hip":
+    if (src.endswith(".hip") and src != "api.hip") or src == "xorwow_tables.cpp":
         obj = os.path.join(out, base)
         subprocess.check_call([B._hipcc()] + B.COMMON + defs + ["-x", "hip", "-c", os.path.join(B.CSRC, src), "-o", obj])
     else:
