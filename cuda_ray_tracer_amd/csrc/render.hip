@@ -42,9 +42,6 @@ constexpr int MAX_SLAB_ARGS = 4;      // device copies of RenderArgs a context c
 #endif
 constexpr int TRACE_BLOCK = MIRT_TRACE_BLOCK;
 constexpr int MAX_CHUNK_SHIFT = 8, MIN_CHUNK_SHIFT = 6;   // a wave takes 64..256 consecutive samples from the frame per atomic
-#ifndef MIRT_DEFAULT_WAVEFRONT
-#define MIRT_DEFAULT_WAVEFRONT 0
-#endif
 #ifndef MIRT_WAVES_PER_SIMD
 #define MIRT_WAVES_PER_SIMD 4   // 128 VGPRs: measured best (2: 86 ms, 3: 76 ms, 4: 68 ms, 5: 79 ms on tenthousand 1080p16)
 #endif
