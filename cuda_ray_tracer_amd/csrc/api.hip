@@ -39,7 +39,7 @@ const OptionDesc OPTIONS[] = {
   {"traversal", &Options::traversal, 0, 2}, {"wavefront", &Options::wavefront, 0, 1},
   {"stack_lds_depth", &Options::stack_lds_depth, -1, 64}, {"refill_k", &Options::refill_k, 1, 64}, {"batch_k", &Options::batch_k, 1, 64},
   {"leaf_k", &Options::leaf_k, 1, 64}, {"reps", &Options::reps, 1, 8}, {"drain_lanes", &Options::drain_lanes, 0, 64},
-  {"chunk_shift", &Options::chunk_shift, 0, 12}, {"trace_waves", &Options::trace_waves, 0, 1 << 20}, {"sched", &Options::sched, 0, 1}, {"slab_log2", &Options::slab_log2, 8, 30},
+  {"chunk_shift", &Options::chunk_shift, 0, 12}, {"trace_waves", &Options::trace_waves, 0, 1 << 20}, {"sched", &Options::sched, 0, 1}, {"qnodes", &Options::qnodes, 0, 1}, {"slab_log2", &Options::slab_log2, 8, 30},
   {"wf_pool", &Options::wf_pool, 256, 1 << 24}, {"wf_refill_k", &Options::wf_refill_k, 1, 64},
 };
 
@@ -190,12 +190,15 @@ int scene_create(const MirtSceneDesc* d, int device, MirtScene** out)
   {
     const size_t nodes_bytes = N > 1 ? 64 * (size_t)(N - 1) : 0;
     const size_t sph_bytes = 16 * (size_t)sc->Ns, tri_bytes = 48 * (size_t)sc->Nt;
-    const size_t total = nodes_bytes + sph_bytes + tri_bytes + 64;
+    // (sphere-only scenes also get 32-byte quantised node records behind the primitives, scene_dev.h)
+    const size_t qnode_bytes = (sc->Nt == 0 && N > 1) ? 32 * (size_t)(N - 1) : 0;
+    const size_t total = nodes_bytes + sph_bytes + tri_bytes + 64 + qnode_bytes;
     if (total > 0xfffffff0ull) { delete sc; set_error("mirt_scene_create: scene too large for 32-bit record offsets"); return MIRT_ERR_ARG; }
     hipError_t e = hipMalloc(&sc->heap, total);
     if (e == hipSuccess) e = hipMemset(sc->heap, 0, total);
     if (e != hipSuccess) { delete sc; return hip_fail(e, "hipMalloc(heap)", __FILE__, __LINE__); }
     sc->prim_base = (uint32_t)nodes_bytes;
+    sc->qnode_base = qnode_bytes ? (uint32_t)(nodes_bytes + sph_bytes + tri_bytes + 64) : 0u;
     sc->nodes = reinterpret_cast<float4*>(sc->heap);
   }
   chk(upload(&sc->spheres, spheres)); chk(upload(&sc->tris, tris));
@@ -210,6 +213,7 @@ int scene_create(const MirtSceneDesc* d, int device, MirtScene** out)
     alloc((void**)&sc->tris_before, 4 * ((size_t)N + 1));
   }
   alloc((void**)&sc->bounds_keys, 6 * 4);
+  alloc((void**)&sc->qparams, 6 * 4);
   for (int i = 0; i < mirt::MIRT_MAX_FRAMES; ++i) {
     alloc((void**)&sc->ctx[i].counters, 16 * sizeof(unsigned long long));
     if (rc == MIRT_OK && hipMemset(sc->ctx[i].counters, 0, 16 * sizeof(unsigned long long)) != hipSuccess) rc = MIRT_ERR_HIP;
@@ -243,7 +247,7 @@ void mirt_scene_destroy(MirtScene* sc)
   hipFree(sc->unit_prim); hipFree(sc->tris_before); hipFree(sc->range);
   hipFree(sc->planes); hipFree(sc->suns); hipFree(sc->bulbs);
   hipFree(sc->codes); hipFree(sc->order); hipFree(sc->child_l); hipFree(sc->child_r); hipFree(sc->parent); hipFree(sc->boxes); hipFree(sc->build_ws);
-  hipFree(sc->bounds_keys);
+  hipFree(sc->bounds_keys); hipFree(sc->qparams);
   for (int i = 0; i < mirt::MIRT_MAX_FRAMES; ++i) {
     mirt::RenderCtx& c = sc->ctx[i];
     hipFree(c.samples); hipFree(c.stack_spill); hipFree(c.pending); hipFree(c.counters); hipFree(c.prof); hipFree(c.args_dev);

@@ -384,6 +384,38 @@ MIRT_DEV uint32_t make_ref(uint32_t node, uint32_t leaf_base, const uint32_t* __
   return 4u * node;
 }
 
+// Quantised node records for sphere-only scenes (scene_dev.h): child boxes on the scene-bounds grid, rounded outwards.
+MIRT_DEV uint32_t qlo(float x, float smin, float step) { const float q = floorf((x - smin) / step) - 1.0f; return (uint32_t)fminf(fmaxf(q, 0.0f), QGRID); }
+MIRT_DEV uint32_t qhi(float x, float smin, float step) { const float q = ceilf((x - smin) / step) + 1.0f; return (uint32_t)fminf(fmaxf(q, 0.0f), QGRID); }
+__global__ void __launch_bounds__(BLOCK) pack_qnodes_kernel(int n, const uint32_t* __restrict__ bkeys, const uint32_t* __restrict__ child_l,
+                                                            const uint32_t* __restrict__ child_r, const float* __restrict__ boxes,
+                                                            uint4* __restrict__ qnodes, float* __restrict__ qparams, uint32_t qbase16, uint32_t prim_base16)
+{
+  const int p = blockIdx.x * BLOCK + threadIdx.x;
+  float smin[3], step[3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    smin[k] = key2f(bkeys[k]);
+    const float range = key2f(bkeys[3 + k]) - smin[k];
+    step[k] = range > 0.0f ? range / QGRID : 1.0f;
+  }
+  if (p == 0) { for (int k = 0; k < 3; ++k) { qparams[k] = smin[k]; qparams[3 + k] = step[k]; } }
+  if (p >= n - 1) return;
+  const uint32_t leaf_base = (uint32_t)(n - 1);
+  const uint32_t c[2] = {child_l[p], child_r[p]};
+  uint32_t w[8];
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {
+    const float* b = boxes + 6 * (size_t)c[s];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) w[3 * s + k] = qlo(b[2 * k], smin[k], step[k]) | (qhi(b[2 * k + 1], smin[k], step[k]) << 16);
+    // (sphere-only scene: sorted leaf j's record is unit j of the primitive region)
+    w[6 + s] = c[s] >= leaf_base ? (REF_LEAF | (prim_base16 + (c[s] - leaf_base))) : (qbase16 + 2u * c[s]);
+  }
+  qnodes[2 * (size_t)p + 0] = make_uint4(w[0], w[1], w[2], w[3]);
+  qnodes[2 * (size_t)p + 1] = make_uint4(w[4], w[5], w[6], w[7]);
+}
+
 // primitive records in sorted order + the unit -> primitive map the shading code uses to find the material
 __global__ void __launch_bounds__(BLOCK) scatter_prims_kernel(int n, const uint32_t* __restrict__ order, const MirtPrimRef* __restrict__ refs,
                                                               const uint32_t* __restrict__ tris_before, const float4* __restrict__ spheres,
@@ -530,6 +562,13 @@ int build_lbvh(MirtScene* sc, hipStream_t stream)
                      reinterpret_cast<float4*>(sc->heap + sc->prim_base), sc->unit_prim);
   hipLaunchKernelGGL(refit_pack_kernel, dim3(nblk), dim3(BLOCK), 0, stream, n, sc->order, sc->refs_in, sc->spheres, sc->tri_verts,
                      sc->child_l, sc->child_r, sc->parent, arrived, sc->boxes, sc->nodes, sc->tris_before, sc->range, sc->prim_base / 16u);
+  sc->root_ref_q = REF_NONE;
+  if (sc->qnode_base && n > 1 && !sc->opt.bounds_as_shipped) {
+    const int kblk = (n - 1 + BLOCK - 1) / BLOCK;
+    hipLaunchKernelGGL(pack_qnodes_kernel, dim3(kblk), dim3(BLOCK), 0, stream, n, sc->bounds_keys, sc->child_l, sc->child_r, sc->boxes,
+                       reinterpret_cast<uint4*>(sc->heap + sc->qnode_base), sc->qparams, sc->qnode_base / 16u, sc->prim_base / 16u);
+    sc->root_ref_q = sc->qnode_base / 16u;
+  }
   MIRT_HIP(hipGetLastError());
   MIRT_HIP(hipEventRecord(sc->ev1, stream));
   MIRT_HIP(hipStreamSynchronize(stream));   // lbvh_builder.cu:475

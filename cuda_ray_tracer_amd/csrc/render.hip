@@ -49,7 +49,8 @@ constexpr int MAX_CHUNK_SHIFT = 8, MIN_CHUNK_SHIFT = 6;   // a wave takes 64..25
 #define MIRT_STACK_LDS 32
 #endif
 constexpr int STACK_LDS = MIRT_STACK_LDS;
-template <bool COUNT, bool PROF, int TABLES>
+// QN: the scene's nodes are 32-byte quantised records (sphere-only scenes, scene_dev.h)
+template <bool COUNT, bool PROF, int TABLES, bool QN>
 __global__ void __launch_bounds__(TRACE_BLOCK, MIRT_WAVES_PER_SIMD) trace_kernel(const RenderArgs* __restrict__ ap, const HotArgs h)
 {
   // PROF: diagnostic build only -- cycle stamps per phase, written to h.prof (never used for timing claims)
@@ -109,8 +110,8 @@ __global__ void __launch_bounds__(TRACE_BLOCK, MIRT_WAVES_PER_SIMD) trace_kernel
     }
     // (once the frame's queue is empty the first ray of a new batch is started by the traversal loop's header instead)
     while (!S.trav && S.g >= 0 && !(exhausted && S.batch_pending)) {
-      if (S.batch_pending) batch_next<COUNT>(a, S, cn);
-      else advance<COUNT>(a, S, cn, gid, gthreads);
+      if (S.batch_pending) batch_next<COUNT, QN>(a, S, cn);
+      else advance<COUNT, QN>(a, S, cn, gid, gthreads);
       if (PROF) pf_adv_it++;
     }
     if (PROF) pf_adv += clock64() - pf_a;
@@ -144,7 +145,7 @@ __global__ void __launch_bounds__(TRACE_BLOCK, MIRT_WAVES_PER_SIMD) trace_kernel
           given += take;
         }
         const unsigned long long pf_i0 = PROF ? clock64() : 0;
-        if (my >= 0) init_sample<COUNT, TABLES>(a, S, cn, my);
+        if (my >= 0) init_sample<COUNT, TABLES, QN>(a, S, cn, my);
         if (PROF) pf_init += clock64() - pf_i0;
       }
     }
@@ -175,7 +176,7 @@ __global__ void __launch_bounds__(TRACE_BLOCK, MIRT_WAVES_PER_SIMD) trace_kernel
       if (bm != 0 && (__popcll(bm) >= h.batch_k || tm == 0 || drain)) {
         if (PROF) { pf_Bent++; pf_Blanes += __popcll(bm); }
         const unsigned long long pf_b0 = PROF ? clock64() : 0;
-        if (!S.trav && S.batch_pending) batch_next<COUNT>(h, S, cn);
+        if (!S.trav && S.batch_pending) batch_next<COUNT, QN>(h, S, cn);
         if (PROF) pf_init += 0, pf_Bcyc += clock64() - pf_b0;
       }
       if (PROF && exhausted) { pf_xit++; pf_xact += __popcll(__ballot(S.trav)); if (drain) pf_dit++; }
@@ -210,7 +211,9 @@ __global__ void __launch_bounds__(TRACE_BLOCK, MIRT_WAVES_PER_SIMD) trace_kernel
             hit = triangle_hit(q0, q1, q2, S.o, S.d, t);
           } else {
             if (COUNT) cn.sphere_tests++;
-            hit = sphere_hit(q0, S.o, S.d, t);
+            float tc, t_far;
+            hit = sphere_hit(q0, S.o, S.d, t, tc, t_far);
+            if (QN && hit) hit = sphere_leaf_box_admits(q0, S.o, S.d, tc, t_far);
           }
           // (S.trav is true here)
           const bool closer = closer_hit(hit, t, S.tbest, S.cur & REF_OFFMASK, S.refbest);
@@ -226,13 +229,23 @@ __global__ void __launch_bounds__(TRACE_BLOCK, MIRT_WAVES_PER_SIMD) trace_kernel
           uint32_t noff = S.cur << 4;
           asm volatile("" : "+v"(noff));
           const float4* nrec = reinterpret_cast<const float4*>(heap + noff);
-          const float4 q0 = nrec[0], q1 = nrec[1], q2 = nrec[2];
-          const uint4 ch = *reinterpret_cast<const uint4*>(nrec + 3);      // child references, NODE_SWAP_* flags
           bool hl, hr;
           float tel, ter;
-          box_pair(q0, q1, q2, S.o.x, S.o.y, S.o.z, S.inv.x, S.inv.y, S.inv.z, S.tbest, tmin, hl, hr, tel, ter);
-          uint32_t lref = ch.x, rref = ch.y;
-          order_children(hl, hr, tel, ter, ch.z, h.swap_mask, lref, rref);
+          uint32_t lref, rref;
+          if (QN) {
+            // two 16-byte requests: twelve grid coordinates and the child references; every node of a sphere-only scene may
+            // be descended near child first
+            const uint4 w0 = *reinterpret_cast<const uint4*>(nrec), w1 = *reinterpret_cast<const uint4*>(nrec + 1);
+            box_pair_q(w0, w1.x, w1.y, S.inv, S.qb, S.tbest, tmin, hl, hr, tel, ter);
+            lref = w1.z; rref = w1.w;
+            order_children(hl, hr, tel, ter, NODE_SWAP_ANY | NODE_SWAP_PURE, h.swap_mask, lref, rref);
+          } else {
+            const float4 q0 = nrec[0], q1 = nrec[1], q2 = nrec[2];
+            const uint4 ch = *reinterpret_cast<const uint4*>(nrec + 3);      // child references, NODE_SWAP_* flags
+            box_pair(q0, q1, q2, S.o.x, S.o.y, S.o.z, S.inv.x, S.inv.y, S.inv.z, S.tbest, tmin, hl, hr, tel, ter);
+            lref = ch.x; rref = ch.y;
+            order_children(hl, hr, tel, ter, ch.z, h.swap_mask, lref, rref);
+          }
           // first child next, push the second (bvh_traversal.cu:149-157: left, right), written with selects: one short
           // branch for the push
           const bool both = hl && hr;
@@ -541,7 +554,7 @@ static int grid_blocks(int device)
   hipDeviceProp_t prop;
   if (hipGetDeviceProperties(&prop, device) != hipSuccess) return 1024;
   int per_cu = 0;
-  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, trace_kernel<false, false, 8>, TRACE_BLOCK, 0) != hipSuccess || per_cu < 1) per_cu = 4 * 256 / TRACE_BLOCK;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, trace_kernel<false, false, 8, false>, TRACE_BLOCK, 0) != hipSuccess || per_cu < 1) per_cu = 4 * 256 / TRACE_BLOCK;
   return prop.multiProcessorCount * per_cu;
 }
 
@@ -676,7 +689,10 @@ static int render_impl(MirtScene* sc, const MirtRenderParams* p, void* d_rgba8, 
   a.stripe_rows = p->stripe_rows; a.num_parts = p->num_parts; a.part = p->part;
   a.sample_first = sample_first; a.sample_count = sample_count; a.seed_per_pixel = per_pixel_seed ? 1 : 0;
   a.nodes = sc->nodes; a.unit_prim = sc->unit_prim; a.mats = sc->mats;
-  a.root_ref = sc->root_ref; a.num_spheres = sc->Ns; a.num_prims = sc->N;
+  // quantised node records: sphere-only scenes, single-kernel path, any order but the reference's own
+  const bool qn = sc->root_ref_q != REF_NONE && opt.qnodes != 0 && opt.traversal >= 1 && opt.wavefront == 0;
+  a.root_ref = qn ? sc->root_ref_q : sc->root_ref; a.num_spheres = sc->Ns; a.num_prims = sc->N;
+  a.qparams = qn ? sc->qparams : nullptr;
   a.prim_base16 = sc->prim_base / 16u;
   a.swap_mask = opt.traversal == 1 ? NODE_SWAP_PURE : (opt.traversal == 2 ? NODE_SWAP_ANY : 0u);
   a.skip_unlit = (sc->colors_finite && sc->d.num_suns + sc->d.num_bulbs <= 32) ? 1 : 0;
@@ -746,7 +762,7 @@ static int render_impl(MirtScene* sc, const MirtRenderParams* p, void* d_rgba8, 
   cx.wf_trace_ms = -1.0f;
   float wf_ms_total = 0.0f;
   HotArgs h;
-  h.nodes = a.nodes; h.root_ref = a.root_ref; h.swap_mask = a.swap_mask;
+  h.nodes = a.nodes; h.root_ref = a.root_ref; h.swap_mask = a.swap_mask; h.qparams = a.qparams;
   h.planes = a.planes; h.num_planes = a.num_planes; h.suns = a.suns; h.num_suns = a.num_suns; h.bulbs = a.bulbs; h.num_bulbs = a.num_bulbs;
   h.stack_spill = a.stack_spill; h.lds_depth = a.lds_depth; h.refill_k = a.refill_k; h.batch_k = a.batch_k; h.drain_lanes = a.drain_lanes;
   h.leaf_k = opt.leaf_k;
@@ -783,18 +799,20 @@ static int render_impl(MirtScene* sc, const MirtRenderParams* p, void* d_rgba8, 
       MIRT_HIP(hipMemcpyAsync(adev, &a, sizeof(RenderArgs), hipMemcpyHostToDevice, stream));
 #if MIRT_DIAG_PROF
       if (prof) {
-        hipLaunchKernelGGL((trace_kernel<false, true, 0>), dim3(blocks), dim3(TRACE_BLOCK), 0, stream, adev, h);
+        hipLaunchKernelGGL((trace_kernel<false, true, 0, false>), dim3(blocks), dim3(TRACE_BLOCK), 0, stream, adev, h);
         int rc = report_prof(cx, blocks, stream);
         if (rc != MIRT_OK) return rc;
       } else
 #endif
-      // one instantiation per form of the random-number tables (device_common.h, xw_init)
+      // one instantiation per form of the random-number tables (device_common.h, xw_init) and per node format
       {
         const bool t8 = a.needs_rng && a.rng.mode == 0 && a.rng.chunk_bits == 8;
-        if (count) { if (t8) hipLaunchKernelGGL((trace_kernel<true, false, 8>), dim3(blocks), dim3(TRACE_BLOCK), 0, stream, adev, h);
-                     else hipLaunchKernelGGL((trace_kernel<true, false, 4>), dim3(blocks), dim3(TRACE_BLOCK), 0, stream, adev, h); }
-        else { if (t8) hipLaunchKernelGGL((trace_kernel<false, false, 8>), dim3(blocks), dim3(TRACE_BLOCK), 0, stream, adev, h);
-               else hipLaunchKernelGGL((trace_kernel<false, false, 4>), dim3(blocks), dim3(TRACE_BLOCK), 0, stream, adev, h); }
+#define MIRT_LAUNCH(C, T, Q) hipLaunchKernelGGL((trace_kernel<C, false, T, Q>), dim3(blocks), dim3(TRACE_BLOCK), 0, stream, adev, h)
+        if (count) { if (qn) { if (t8) MIRT_LAUNCH(true, 8, true); else MIRT_LAUNCH(true, 4, true); }
+                     else    { if (t8) MIRT_LAUNCH(true, 8, false); else MIRT_LAUNCH(true, 4, false); } }
+        else       { if (qn) { if (t8) MIRT_LAUNCH(false, 8, true); else MIRT_LAUNCH(false, 4, true); }
+                     else    { if (t8) MIRT_LAUNCH(false, 8, false); else MIRT_LAUNCH(false, 4, false); } }
+#undef MIRT_LAUNCH
       }
     }
     MIRT_HIP(hipGetLastError());

@@ -22,6 +22,14 @@ constexpr uint32_t REF_LEAF = 0x80000000u;
 constexpr uint32_t REF_TRI = 0x40000000u;
 constexpr uint32_t REF_OFFMASK = 0x0fffffffu;  // the record's offset in the heap, in 16-byte units: `ref << 4` is its byte offset (the shift drops the flags)
 constexpr uint32_t REF_NONE = 0xf0000000u;   // no record (bits 29..28 are set in no real reference; offset bits 0)
+// Quantised node records (sphere-only scenes, option "qnodes"): 32 bytes instead of 64, i.e. two 16-byte requests per node
+// visit instead of four -- the address units are what bounds the trace kernel.  Both child boxes as 12 x uint16 on the
+// scene-bounds grid (65535 steps per axis, rounded outwards by one more step), then the two child references.  The boxes are
+// supersets of the exact ones: for spheres the closest hit cannot change (shade_common.h, sphere_leaf_box_admits restores the
+// one clause of the reference's box test that a larger box weakens); the visit counters do (+0.13 % node visits on the bundled scenes).
+//   words 0..2 child 0: (xmin | xmax << 16), (ymin | ymax << 16), (zmin | zmax << 16); words 3..5 child 1; 6, 7: references
+// Node i sits at heap offset qnode_base + 32 i: its reference is qnode_base / 16 + 2 i.
+constexpr float QGRID = 65535.0f;
 // node record word 14 (after the two child references): which descent orders the node allows
 constexpr uint32_t NODE_SWAP_PURE = 1u;       // both subtrees hold spheres only: near-child-first cannot change the closest hit
 constexpr uint32_t NODE_SWAP_ANY = 2u;        // always set (the mask of MIRT_TRAVERSAL_ORDERED_ALL)
@@ -55,6 +63,7 @@ struct RenderArgs {
   uint32_t prim_base16;           // offset of the primitive region in the heap, in 16-byte units
   uint32_t swap_mask;             // NODE_SWAP_* bits that allow near-child-first descent (0: the reference's left-first order)
   int skip_unlit;                 // 1: shadow rays towards lights the shading normal faces away from are not traced (all colours finite)
+  const float* qparams;           // quantised nodes in use: grid origin xyz, grid step xyz (else null)
   int num_spheres;
   int num_prims;
   const PlaneDev* planes; int num_planes;
@@ -88,6 +97,7 @@ struct HotArgs {
   const float4* nodes;            // start of the record heap
   uint32_t root_ref;
   uint32_t swap_mask;
+  const float* qparams;
   const PlaneDev* planes; int num_planes;
   const LightDev* suns; int num_suns;
   const LightDev* bulbs; int num_bulbs;
@@ -128,6 +138,7 @@ struct Options {
   int batch_k = 8, leaf_k = 8, reps = 4, drain_lanes = 16;
   int chunk_shift = 0;         // 0: by frame size
   int trace_waves = 0;         // 0: fill the device
+  int qnodes = 1;              // sphere-only scenes: 32-byte quantised node records in the single-kernel path (traversal >= 1)
   int sched = 1;               // longest-first chunk order measured on earlier frames
   int slab_log2 = 26;          // a call is rendered in slabs of at most 2^slab_log2 samples (1 GiB of per-sample workspace)
   int wf_pool = 1 << 21, wf_refill_k = 16;
@@ -190,6 +201,9 @@ struct MirtScene {
   uint32_t* unit_prim = nullptr;        // [Ns + 3 Nt]: per 16-byte unit of the primitive region, type << 31 | index (first unit of a record)
   uint32_t* tris_before = nullptr;      // [N + 1]: triangles among sorted leaves [0, j)
   uint2* range = nullptr;               // [N - 1]: sorted-leaf range (first, last) of every internal node
+  uint32_t qnode_base = 0;              // byte offset of the quantised node records in the heap (0: none built)
+  uint32_t root_ref_q = mirt::REF_NONE; // root reference into the quantised records
+  float* qparams = nullptr;             // [6] device: grid origin, grid step
   uint32_t* build_ws = nullptr; size_t build_ws_words = 0;   // LBVH build workspace (sort buffers, histograms, arrival counters)
   uint32_t* bounds_keys = nullptr;      // [6] ordered-uint min xyz, max xyz
   uint32_t root_ref = mirt::REF_NONE;

@@ -126,6 +126,50 @@ MIRT_DEV void box_pair(const float4 q0, const float4 q1, const float4 q2, float 
   ter = te;
 }
 
+// The same test on a quantised node record (scene_dev.h): a box plane is grid_origin + q * grid_step, so its ray parameter is
+// q * A + B with A = grid_step * inv_dir and B = (grid_origin - origin) * inv_dir, both set up once per ray (start_ray): one
+// fused multiply-add per plane.  (A zero direction component gives NaN parameters, which fminf / fmaxf drop: the axis is then
+// ignored, a superset like the outward rounding of the boxes themselves.)
+MIRT_DEV void box_pair_q(const uint4 w0, const uint32_t w4, const uint32_t w5, const f3& A, const f3& B, float tbest, float tmin,
+                         bool& hl, bool& hr, float& tel, float& ter)
+{
+  // (scalar fused multiply-adds: the packed form, v_pk_fma_f32, cost three more live registers and put spills into the loop
+  // header: 26.7 -> 28.6 ms)
+#define MIRT_QT(w, a, b, lo, hi) const float lo = __builtin_fmaf((float)((w) & 0xffffu), a, b), hi = __builtin_fmaf((float)((w) >> 16), a, b)
+  MIRT_QT(w0.x, A.x, B.x, lx0, lx1); MIRT_QT(w0.y, A.y, B.y, ly0, ly1); MIRT_QT(w0.z, A.z, B.z, lz0, lz1);
+  MIRT_QT(w0.w, A.x, B.x, rx0, rx1); MIRT_QT(w4, A.y, B.y, ry0, ry1);   MIRT_QT(w5, A.z, B.z, rz0, rz1);
+#undef MIRT_QT
+  float te = fmaxf(fmaxf(fminf(lx0, lx1), fminf(ly0, ly1)), fminf(lz0, lz1));
+  float tx = fminf(fminf(fmaxf(lx0, lx1), fmaxf(ly0, ly1)), fmaxf(lz0, lz1));
+  hl = te < tx && te < tbest && tx > tmin;
+  tel = te;
+  te = fmaxf(fmaxf(fminf(rx0, rx1), fminf(ry0, ry1)), fminf(rz0, rz1));
+  tx = fminf(fminf(fmaxf(rx0, rx1), fmaxf(ry0, ry1)), fmaxf(rz0, rz1));
+  hr = te < tx && te < tbest && tx > tmin;
+  ter = te;
+}
+
+// A sphere reached through quantised (larger) boxes skipped part of the box test its leaf gets in the reference's walk.  For a
+// sphere that is hit, that test (bvh_traversal.cu:11-44) can only fail through its `t_exit > t_min` clause: the ray leaves the
+// sphere's box within 1e-4 of its origin (it starts inside an overlapping sphere, just under its surface) and the reference
+// does not see the hit.  The far intersection t_far bounds the box's exit from below, so t_far comfortably above 1e-4 settles
+// it; otherwise the box test is evaluated exactly as the reference does (the leaf box is c -+ r, lbvh_builder.cu:33-41).
+MIRT_DEV bool sphere_leaf_box_admits(const float4 q, const f3& o, const f3& d, float tc, float t_far)
+{
+  if (t_far > 0.0001f + 1e-5f * (fabsf(tc) + fabsf(q.w))) return true;
+  const f3 inv = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+  const float ax = q.x - q.w, bx = q.x + q.w, ay = q.y - q.w, by = q.y + q.w, az = q.z - q.w, bz = q.z + q.w;
+  const float xmin = (ax <= bx) ? ax : bx, xmax = (ax <= bx) ? bx : ax;
+  const float ymin = (ay <= by) ? ay : by, ymax = (ay <= by) ? by : ay;
+  const float zmin = (az <= bz) ? az : bz, zmax = (az <= bz) ? bz : az;
+  const float tx1 = (xmin - o.x) * inv.x, tx2 = (xmax - o.x) * inv.x;
+  const float ty1 = (ymin - o.y) * inv.y, ty2 = (ymax - o.y) * inv.y;
+  const float tz1 = (zmin - o.z) * inv.z, tz2 = (zmax - o.z) * inv.z;
+  const float te = fmaxf(fmaxf(fminf(tx1, tx2), fminf(ty1, ty2)), fminf(tz1, tz2));
+  const float tx = fminf(fminf(fmaxf(tx1, tx2), fmaxf(ty1, ty2)), fmaxf(tz1, tz2));
+  return te < tx && tx > 0.0001f;
+}
+
 // The descent order at a node whose children are both hit.  The reference goes left first (bvh_traversal.cu:149-157).  Where the
 // node's record allows it (NODE_SWAP_* & swap_mask) the child whose box the ray enters first is taken first instead: fewer
 // visits, the same closest hit (see closer_hit).  Returns the two references in visiting order.
@@ -164,7 +208,7 @@ MIRT_DEV bool triangle_hit(const float4 q0, const float4 q1, const float4 q2, co
 }
 
 // checkSphereIntersectionSoA, struct.cu:64-109 (same remark)
-MIRT_DEV bool sphere_hit(const float4 q, const f3& o, const f3& d, float& t)
+MIRT_DEV bool sphere_hit(const float4 q, const f3& o, const f3& d, float& t, float& tc_out, float& t_far)
 {
   const f3 c = mk3(q.x, q.y, q.z);
   const float r = q.w;
@@ -175,6 +219,7 @@ MIRT_DEV bool sphere_hit(const float4 q, const f3& o, const f3& d, float& t)
   const float d2 = dot(dv, dv);
   const float toff = sqrtf((r * r) - d2);
   t = inside ? (tc + toff) : (tc - toff);
+  tc_out = tc; t_far = tc + toff;
   return !(!inside && tc < 0.0f) && !(!inside && (r * r) < d2);
 }
 
@@ -201,7 +246,8 @@ struct Lane {
   unsigned long long occl;     // bit i: light i is occluded
   bool batch_pending, has_reflect;
   // ray in flight
-  f3 o, d, inv;
+  f3 o, d, inv;       // (with quantised nodes `inv` holds A = grid_step / d and qb holds B = (grid_origin - o) / d, see box_pair_q)
+  f3 qb;
   int bounce;
   float limit;        // shadow rays: occluded iff something is hit closer than this
   bool shadow;
@@ -217,13 +263,19 @@ struct Lane {
 };
 
 // hitNearest's plane half (checkPlane, draw.cu:581-615) and the decision whether the BVH must be walked at all.
-template <bool COUNT, bool HAVE_INV = false, typename Args = RenderArgs>
+template <bool COUNT, bool HAVE_INV = false, bool QN = false, typename Args = RenderArgs>
 MIRT_DEV void start_ray(const Args& a, Lane& S, Counters& cn)
 {
   const bool shadow = S.shadow;
   if (COUNT) { cn.rays++; if (shadow) cn.shadow_rays++; }
-
   if (!HAVE_INV) S.inv = mk3(1.0f / S.d.x, 1.0f / S.d.y, 1.0f / S.d.z);
+  if (QN) {
+    // the ray in the grid of the quantised node records (uniform values: scalar loads)
+    typedef const float __attribute__((address_space(4))) * ConstF;
+    const ConstF qp = (ConstF)(unsigned long long)a.qparams;
+    S.qb = mk3((qp[0] - S.o.x) * S.inv.x, (qp[1] - S.o.y) * S.inv.y, (qp[2] - S.o.z) * S.inv.z);
+    S.inv = mk3(qp[3] * S.inv.x, qp[4] * S.inv.y, qp[5] * S.inv.z);
+  }
   float tplane = INFINITY;
   int plane_id = -1;
   // (the planes are the same for every lane and never written by a kernel: read them through the constant address space,
@@ -270,7 +322,7 @@ MIRT_DEV uint32_t unlit_mask(const Args& a, const f3& pn, const f3& Hp)
 // The ray of the batch that was in flight has finished: note a shadow result, start the next ray of the batch
 // (shadow rays of diffuseLight, draw.cu:342-374, then the reflection ray of reflectionLight, draw.cu:402-404).
 // Shadow rays consume no random numbers, so tracing them after the reflection direction was drawn changes nothing.
-template <bool COUNT, typename Args = RenderArgs>
+template <bool COUNT, bool QN = false, typename Args = RenderArgs>
 MIRT_DEV void batch_next(const Args& a, Lane& S, Counters& cn)
 {
   const int nlights = a.num_suns + a.num_bulbs;
@@ -319,7 +371,7 @@ MIRT_DEV void batch_next(const Args& a, Lane& S, Counters& cn)
     S.shadow = false;
     S.trav = false;
   }
-  if (go) start_ray<COUNT, true>(a, S, cn);
+  if (go) start_ray<COUNT, true, QN>(a, S, cn);
 }
 
 // Consume the finished trace of lane S and run its shading state machine until it either has the next ray(s) or the
@@ -522,7 +574,7 @@ MIRT_DEV int advance_core(const RenderArgs& a, Lane& S, Counters& cn, const long
 }
 
 // Megakernel form: consume the finished trace, shade, and start the next ray of this lane (or finish the sample).
-template <bool COUNT>
+template <bool COUNT, bool QN = false>
 MIRT_DEV void advance(const RenderArgs& a, Lane& S, Counters& cn, const long long gid, const long long gthreads)
 {
   const int micro = advance_core<COUNT>(a, S, cn, gid, gthreads);
@@ -537,11 +589,11 @@ MIRT_DEV void advance(const RenderArgs& a, Lane& S, Counters& cn, const long lon
     S.g = -1;
     S.trav = false;
   } else if (micro == M_BATCH) {
-    batch_next<COUNT>(a, S, cn);
+    batch_next<COUNT, QN>(a, S, cn);
   } else {
     S.shadow = false;
     S.limit = INFINITY;
-    start_ray<COUNT>(a, S, cn);
+    start_ray<COUNT, false, QN>(a, S, cn);
   }
 }
 
@@ -584,7 +636,7 @@ MIRT_DEV void init_sample_core(const RenderArgs& a, Lane& S, Counters& cn, const
   if (COUNT) cn.samples++;
 }
 
-template <bool COUNT, int TABLES = 0>
+template <bool COUNT, int TABLES = 0, bool QN = false>
 MIRT_DEV void init_sample(const RenderArgs& a, Lane& S, Counters& cn, const long long idx)
 {
   init_sample_core<COUNT, TABLES>(a, S, cn, idx);
@@ -593,7 +645,7 @@ MIRT_DEV void init_sample(const RenderArgs& a, Lane& S, Counters& cn, const long
     S.g = -1;
     S.trav = false;
   } else {
-    start_ray<COUNT>(a, S, cn);
+    start_ray<COUNT, false, QN>(a, S, cn);
   }
 }
 

@@ -394,7 +394,8 @@ __global__ void __launch_bounds__(WBLOCK, MIRT_WF_WAVES_PER_SIMD) wf_trace_kerne
         } else {
           if (COUNT) cn.sphere_tests++;
           float t;
-          const bool hit = sphere_hit(q0, o, d, t);
+          float tc_, tf_;
+          const bool hit = sphere_hit(q0, o, d, t, tc_, tf_);
           if (closer_hit(hit, t, tbest, off16, refbest)) {
             tbest = t; refbest = cur;
             if (shadow && tbest < limit) trav = false;

@@ -97,6 +97,11 @@ typedef struct {
  * does this when every colour is finite): the light's term is colour * light * max(dot, 0) = 0 whether it is occluded
  * or not (draw.cu:353-357, 371-374).  The ray still counts as a ray; it visits no node. */
 #define ORC_FLAG_SKIP_UNLIT    16u
+/* Quantised node records (the product's single-kernel path on sphere-only scenes, scene_dev.h): child boxes on the 65535-step
+ * grid of the scene bounds, rounded outwards, tested with one fused multiply-add per plane; a sphere hit then has to pass the
+ * `t_enter < t_exit && t_exit > t_min` clauses of its exact leaf box (bvh_traversal.cu:43), which the larger boxes weaken.
+ * Same closest hit as the exact boxes; more node visits.  Only meaningful with ORDERED / ORDERED_ALL and without triangles. */
+#define ORC_FLAG_QNODES        32u
 #define ORC_FLAG_ORDERED       4u
 #define ORC_FLAG_ORDERED_ALL   8u   /* near child first at every node (triangle silhouettes may differ from the reference order) */
 
@@ -668,6 +673,20 @@ static inline bool hit_aabb_t(const ONode& b, const V3& o, const V3& inv, float 
   return t_enter < t_exit && t_enter < tmax && t_exit > tmin;
 }
 
+static inline uint32_t q_lo(float x, float smin, float step) { float q = floorf((x - smin) / step) - 1.0f; return (uint32_t)fminf(fmaxf(q, 0.0f), 65535.0f); }
+static inline uint32_t q_hi(float x, float smin, float step) { float q = ceilf((x - smin) / step) + 1.0f; return (uint32_t)fminf(fmaxf(q, 0.0f), 65535.0f); }
+/* box test on the quantised form of box b: plane parameter = q * A + B (one rounding), A = step * inv, B = (smin - o) * inv */
+static inline bool hit_qbox(const ONode& b, const float* smin, const float* step, const V3& A, const V3& B, float tmin, float tmax, float* te)
+{
+  float x0 = fmaf((float)q_lo(b.xmin, smin[0], step[0]), A.x, B.x), x1 = fmaf((float)q_hi(b.xmax, smin[0], step[0]), A.x, B.x);
+  float y0 = fmaf((float)q_lo(b.ymin, smin[1], step[1]), A.y, B.y), y1 = fmaf((float)q_hi(b.ymax, smin[1], step[1]), A.y, B.y);
+  float z0 = fmaf((float)q_lo(b.zmin, smin[2], step[2]), A.z, B.z), z1 = fmaf((float)q_hi(b.zmax, smin[2], step[2]), A.z, B.z);
+  float t_enter = fmaxf(fmaxf(fminf(x0, x1), fminf(y0, y1)), fminf(z0, z1));
+  float t_exit = fminf(fminf(fmaxf(x0, x1), fmaxf(y0, y1)), fmaxf(z0, z1));
+  *te = t_enter;
+  return t_enter < t_exit && t_enter < tmax && t_exit > tmin;
+}
+
 /* traverse() with the product's near-child-first descent (see ORC_FLAG_ORDERED above): same closest hit as traverse(),
  * fewer node visits. */
 static Obj traverse_ordered(Ctx& cx, const Ray& ray, float initial_t_max, bool early, float stop_below)
@@ -686,6 +705,11 @@ static Obj traverse_ordered(Ctx& cx, const Ray& ray, float initial_t_max, bool e
   uint32_t stack[64];
   int sp = 0;
   uint32_t cur = 0;
+  const bool qn = (cx.flags & ORC_FLAG_QNODES) != 0 && N > 1;      /* (a single primitive has no node records) */
+  float qstep[3];
+  for (int k = 0; k < 3; ++k) { float range = sc.smax[k] - sc.smin[k]; qstep[k] = range > 0.0f ? range / 65535.0f : 1.0f; }
+  const V3 qB = mk((sc.smin[0] - ray.eye.x) * inv.x, (sc.smin[1] - ray.eye.y) * inv.y, (sc.smin[2] - ray.eye.z) * inv.z);
+  const V3 qA = mk(qstep[0] * inv.x, qstep[1] * inv.y, qstep[2] * inv.z);
   while (true) {
     const ONode& node = sc.nodes[cur];
     cx.st.node_iters++;
@@ -693,7 +717,18 @@ static Obj traverse_ordered(Ctx& cx, const Ray& ray, float initial_t_max, bool e
       const uint32_t k = node.prim_offset;
       const OPrimRef& ref = sc.refs[k];
       Obj h;
-      if (ref.type == 0) { h = check_sphere(cx, ray, ref.id); cx.st.sphere_tests++; }
+      if (ref.type == 0) {
+        h = check_sphere(cx, ray, ref.id); cx.st.sphere_tests++;
+        if (qn && h.isHit) {      /* the two order-independent clauses of the exact leaf box test */
+          float te;
+          hit_aabb_t(node, ray.eye, inv, tmin, INFINITY, &te);
+          float tx1 = (node.xmin - ray.eye.x) * inv.x, tx2 = (node.xmax - ray.eye.x) * inv.x;
+          float ty1 = (node.ymin - ray.eye.y) * inv.y, ty2 = (node.ymax - ray.eye.y) * inv.y;
+          float tz1 = (node.zmin - ray.eye.z) * inv.z, tz2 = (node.zmax - ray.eye.z) * inv.z;
+          float t_exit = fminf(fminf(fmaxf(tx1, tx2), fmaxf(ty1, ty2)), fmaxf(tz1, tz2));
+          if (!(te < t_exit && t_exit > tmin)) h.isHit = false;
+        }
+      }
       else { h = check_triangle(cx, ray, ref.id); cx.st.tri_tests++; }
       if (h.isHit && h.distance > 1e-6f && (h.distance < tmax || (have && h.distance == tmax && k < best_leaf))) {
         tmax = h.distance; best = h; best_leaf = k; have = true;
@@ -706,8 +741,8 @@ static Obj traverse_ordered(Ctx& cx, const Ray& ray, float initial_t_max, bool e
     cx.st.internal_visits++;
     uint32_t l = node.left, r = node.right;
     float tl, tr;
-    bool hl = hit_aabb_t(sc.nodes[l], ray.eye, inv, tmin, tmax, &tl);
-    bool hr = hit_aabb_t(sc.nodes[r], ray.eye, inv, tmin, tmax, &tr);
+    bool hl = qn ? hit_qbox(sc.nodes[l], sc.smin, qstep, qA, qB, tmin, tmax, &tl) : hit_aabb_t(sc.nodes[l], ray.eye, inv, tmin, tmax, &tl);
+    bool hr = qn ? hit_qbox(sc.nodes[r], sc.smin, qstep, qA, qB, tmin, tmax, &tr) : hit_aabb_t(sc.nodes[r], ray.eye, inv, tmin, tmax, &tr);
     if (hl && hr) {
       bool swap = false;
       if (order_pure && tr < tl) {

@@ -15,8 +15,17 @@ FLAG_ORDERED_ALL = 8    # near child first everywhere
 FLAG_SKIP_UNLIT = 16    # shadow rays towards lights the shading normal faces away from are not traced (their term is 0)
 # what libmirt does: any-hit shadow rays and no shadow rays to unlit lights, always; ordered traversal
 # where pixels cannot change, by default -- the oracle mirrors each so that the visit counters can be compared with ==
+FLAG_QNODES = 32        # quantised node records (sphere-only scenes, single-kernel path, traversal >= 1)
 PRODUCT_ALWAYS = FLAG_ANYHIT_SHADOW | FLAG_SKIP_UNLIT
 PRODUCT_FLAGS = PRODUCT_ALWAYS | FLAG_ORDERED
+
+
+def product_flags(scene_has_triangles, traversal=1, wavefront=False, qnodes=True):
+    """The oracle flags that mirror what libmirt does for a scene and option set (for counters to compare with ==)."""
+    f = PRODUCT_ALWAYS | {0: 0, 1: FLAG_ORDERED, 2: FLAG_ORDERED_ALL}[traversal]
+    if qnodes and not scene_has_triangles and traversal >= 1 and not wavefront:
+        f |= FLAG_QNODES
+    return f
 
 
 class V3(C.Structure):

@@ -10,9 +10,14 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "tools"))
 
 
-def test_no_scratch_reloads_on_the_traversal_loop_hot_path():
+import pytest
+
+
+@pytest.mark.parametrize("kernel", ["trace_kernelILb0ELb0ELi8ELb1E", "trace_kernelILb0ELb0ELi8ELb0E"])
+def test_no_scratch_reloads_on_the_traversal_loop_hot_path(kernel):
+    """Both node formats of the 16-spp kernel: quantised records (sphere-only scenes: the headline) and 64-byte records."""
     import hotloop
-    res, cnt, spills = hotloop.analyze()
+    res, cnt, spills = hotloop.analyze(kernel=kernel)
     occ = [r for r in res if r.startswith("Occupancy")]
     assert occ and occ[0].rsplit(":", 1)[1].strip() == "4", res      # 4 waves per SIMD
     scratch = [t for _, t in spills if t.startswith("scratch_")]

@@ -28,7 +28,7 @@ def run_case(text, w, h, spp, **options):
     tree = raw.tree() if stl.num_prims > 0 else None
     raw.close()
     o = ol.OracleScene(pyscene.parse_lines(text.split("\n")), bounds_mode=0)
-    ref = o.render(w, h, spp, flags=ol.PRODUCT_FLAGS, nthreads=8)
+    ref = o.render(w, h, spp, flags=ol.product_flags(stl.num_triangles > 0), nthreads=8)
     if tree is not None:
         on = o.nodes()
         for f in ("left", "right"):

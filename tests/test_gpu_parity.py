@@ -122,7 +122,7 @@ def test_small_frames_match_oracle(name, w, h, spp, gpu_scenes, oracle_scenes):
     stl, raw = gpu_scenes(name)
     gu8, gf = gpu_render(raw, w, h, spp, counters=True)
     st = raw.stats()
-    ref = oracle_scenes(name).render(w, h, spp, flags=ol.PRODUCT_FLAGS, nthreads=8)
+    ref = oracle_scenes(name).render(w, h, spp, flags=ol.product_flags(stl.num_triangles > 0), nthreads=8)
     check_image(gu8, gf, ref)
     os_ = ref["stats"]
     for k in ("samples", "rays", "shadow_rays", "internal_visits", "sphere_tests", "tri_tests", "mat_fetches", "max_stack"):
@@ -259,7 +259,7 @@ def test_wavefront_path_matches_oracle(name, w, h, spp, gpu_scenes, oracle_scene
     with options(raw, wavefront=1, wf_pool=4096):      # small pool: many rounds, slots refilled many times
         gu8, gf = gpu_render(raw, w, h, spp, counters=True)
         st = raw.stats()
-    ref = oracle_scenes(name).render(w, h, spp, flags=ol.PRODUCT_FLAGS, nthreads=8)
+    ref = oracle_scenes(name).render(w, h, spp, flags=ol.product_flags(stl.num_triangles > 0, wavefront=True), nthreads=8)
     check_image(gu8, gf, ref)
     for k in ("samples", "rays", "shadow_rays", "internal_visits", "sphere_tests", "tri_tests", "mat_fetches", "max_stack"):
         assert st[k] == ref["stats"][k], (k, st[k], ref["stats"][k])
@@ -282,7 +282,7 @@ def test_every_traversal_mode_matches_its_oracle_mirror(name, w, h, spp, travers
     with options(raw, traversal=traversal):
         gu8, gf = gpu_render(raw, w, h, spp, counters=True)
         st = raw.stats()
-    flags = ol.PRODUCT_ALWAYS | {0: 0, 1: ol.FLAG_ORDERED, 2: ol.FLAG_ORDERED_ALL}[traversal]
+    flags = ol.product_flags(stl.num_triangles > 0, traversal=traversal)
     ref = oracle_scenes(name).render(w, h, spp, flags=flags, nthreads=8)
     check_image(gu8, gf, ref)
     for k in COUNTER_KEYS:

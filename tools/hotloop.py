@@ -19,9 +19,11 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."
 from cuda_ray_tracer_amd import build as B   # noqa: E402
 
 
-def analyze(defines=()):
+def analyze(defines=(), kernel="trace_kernelILb0ELb0ELi8ELb1E"):
     """Returns (resources, counts, spills): the kernel's resource usage lines, instruction counts by class inside the
-    traversal loop, and [(position, instruction)] of every spill instruction in it."""
+    traversal loop, and [(position, instruction)] of every spill instruction in it.  `kernel`: the mangled instantiation,
+    trace_kernel<COUNT, PROF, TABLES, QN>: ...Li8ELb1E = byte-indexed RNG tables, quantised nodes (the headline scene's
+    kernel); ...Li8ELb0E = 64-byte node records (scenes with triangles)."""
     out = os.path.join(tempfile.gettempdir(), "mirt_hotloop.s")
     cmd = [B._hipcc()] + [c for c in B.COMMON if c != "-fPIC"] + list(defines) + ["-x", "hip", "-S", "--cuda-device-only", os.path.join(B.CSRC, "render.hip"),
                                                                                "-o", out, "-Rpass-analysis=kernel-resource-usage"]
@@ -31,12 +33,12 @@ def analyze(defines=()):
     res, want = [], False
     for line in r.stderr.splitlines():
         if "Function Name" in line:
-            want = "trace_kernelILb0ELb0ELi8E" in line
+            want = kernel in line
         elif want and re.search(r"VGPRs:|SGPRs:|Spill|ScratchSize|Occupancy", line):
             res.append(line.split("remark:")[1].rsplit("[-Rpass", 1)[0].strip())
     body, inside = [], False
     for l in open(out).read().splitlines():
-        if re.match(r"^_ZN4mirt.*trace_kernelILb0ELb0ELi8E.*:", l):
+        if re.match(r"^_ZN4mirt.*" + kernel + r".*:", l):
             inside = True
             continue
         if inside and "s_endpgm" in l:
@@ -103,7 +105,9 @@ def analyze(defines=()):
 
 
 if __name__ == "__main__":
-    res, cnt, spills = analyze(sys.argv[1:])
+    args = [a for a in sys.argv[1:] if a.startswith("-")]
+    kern = [a for a in sys.argv[1:] if not a.startswith("-")]
+    res, cnt, spills = analyze(args, *kern)
     print("\n".join(res))
     print("static instruction counts inside the traversal loop:", cnt)
     print("spill instructions in the loop (position: instruction):")
