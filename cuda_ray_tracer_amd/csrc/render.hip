@@ -236,7 +236,7 @@ __global__ void __launch_bounds__(TRACE_BLOCK, MIRT_WAVES_PER_SIMD) trace_kernel
             // two 16-byte requests: twelve grid coordinates and the child references; every node of a sphere-only scene may
             // be descended near child first
             const uint4 w0 = *reinterpret_cast<const uint4*>(nrec), w1 = *reinterpret_cast<const uint4*>(nrec + 1);
-            box_pair_q(w0, w1.x, w1.y, S.inv, S.qb, S.tbest, tmin, hl, hr, tel, ter);
+            box_pair_q(w0, w1.x, w1.y, S.inv, S.qb, S.qc, S.tbest, tmin, hl, hr, tel, ter);
             lref = w1.z; rref = w1.w;
             order_children(hl, hr, tel, ter, NODE_SWAP_ANY | NODE_SWAP_PURE, h.swap_mask, lref, rref);
           } else {

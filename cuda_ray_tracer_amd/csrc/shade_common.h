@@ -130,14 +130,17 @@ MIRT_DEV void box_pair(const float4 q0, const float4 q1, const float4 q2, float 
 // q * A + B with A = grid_step * inv_dir and B = (grid_origin - origin) * inv_dir, both set up once per ray (start_ray): one
 // fused multiply-add per plane.  (A zero direction component gives NaN parameters, which fminf / fmaxf drop: the axis is then
 // ignored, a superset like the outward rounding of the boxes themselves.)
-MIRT_DEV void box_pair_q(const uint4 w0, const uint32_t w4, const uint32_t w5, const f3& A, const f3& B, float tbest, float tmin,
+// The two planes of an axis use separate offsets B_lo / B_hi: start_ray moves the one of the plane the ray meets first down and
+// the other one up by a bound on the rounding error of q * A + B, so that the box the kernel tests contains the grid box for
+// any ray origin, however far from the scene (origins on an infinite plane are).
+MIRT_DEV void box_pair_q(const uint4 w0, const uint32_t w4, const uint32_t w5, const f3& A, const f3& Blo, const f3& Bhi, float tbest, float tmin,
                          bool& hl, bool& hr, float& tel, float& ter)
 {
   // (scalar fused multiply-adds: the packed form, v_pk_fma_f32, cost three more live registers and put spills into the loop
   // header: 26.7 -> 28.6 ms)
-#define MIRT_QT(w, a, b, lo, hi) const float lo = __builtin_fmaf((float)((w) & 0xffffu), a, b), hi = __builtin_fmaf((float)((w) >> 16), a, b)
-  MIRT_QT(w0.x, A.x, B.x, lx0, lx1); MIRT_QT(w0.y, A.y, B.y, ly0, ly1); MIRT_QT(w0.z, A.z, B.z, lz0, lz1);
-  MIRT_QT(w0.w, A.x, B.x, rx0, rx1); MIRT_QT(w4, A.y, B.y, ry0, ry1);   MIRT_QT(w5, A.z, B.z, rz0, rz1);
+#define MIRT_QT(w, a, b0, b1, lo, hi) const float lo = __builtin_fmaf((float)((w) & 0xffffu), a, b0), hi = __builtin_fmaf((float)((w) >> 16), a, b1)
+  MIRT_QT(w0.x, A.x, Blo.x, Bhi.x, lx0, lx1); MIRT_QT(w0.y, A.y, Blo.y, Bhi.y, ly0, ly1); MIRT_QT(w0.z, A.z, Blo.z, Bhi.z, lz0, lz1);
+  MIRT_QT(w0.w, A.x, Blo.x, Bhi.x, rx0, rx1); MIRT_QT(w4, A.y, Blo.y, Bhi.y, ry0, ry1);   MIRT_QT(w5, A.z, Blo.z, Bhi.z, rz0, rz1);
 #undef MIRT_QT
   float te = fmaxf(fmaxf(fminf(lx0, lx1), fminf(ly0, ly1)), fminf(lz0, lz1));
   float tx = fminf(fminf(fmaxf(lx0, lx1), fmaxf(ly0, ly1)), fmaxf(lz0, lz1));
@@ -246,8 +249,8 @@ struct Lane {
   unsigned long long occl;     // bit i: light i is occluded
   bool batch_pending, has_reflect;
   // ray in flight
-  f3 o, d, inv;       // (with quantised nodes `inv` holds A = grid_step / d and qb holds B = (grid_origin - o) / d, see box_pair_q)
-  f3 qb;
+  f3 o, d, inv;       // (with quantised nodes `inv` holds A = grid_step / d, qb / qc the offsets B_lo / B_hi of box_pair_q)
+  f3 qb, qc;
   int bounce;
   float limit;        // shadow rays: occluded iff something is hit closer than this
   bool shadow;
@@ -273,8 +276,15 @@ MIRT_DEV void start_ray(const Args& a, Lane& S, Counters& cn)
     // the ray in the grid of the quantised node records (uniform values: scalar loads)
     typedef const float __attribute__((address_space(4))) * ConstF;
     const ConstF qp = (ConstF)(unsigned long long)a.qparams;
-    S.qb = mk3((qp[0] - S.o.x) * S.inv.x, (qp[1] - S.o.y) * S.inv.y, (qp[2] - S.o.z) * S.inv.z);
-    S.inv = mk3(qp[3] * S.inv.x, qp[4] * S.inv.y, qp[5] * S.inv.z);
+    const f3 B = mk3((qp[0] - S.o.x) * S.inv.x, (qp[1] - S.o.y) * S.inv.y, (qp[2] - S.o.z) * S.inv.z);
+    const f3 A = mk3(qp[3] * S.inv.x, qp[4] * S.inv.y, qp[5] * S.inv.z);
+    // |q * A + B - exact| <= a few ulp of (65535 |A| + |B|): 2^-21 of it covers the roundings of A, B and the fma
+    const f3 e = mk3((fabsf(B.x) + QGRID * fabsf(A.x)) * 4.76837158203125e-07f, (fabsf(B.y) + QGRID * fabsf(A.y)) * 4.76837158203125e-07f,
+                     (fabsf(B.z) + QGRID * fabsf(A.z)) * 4.76837158203125e-07f);
+    // the low grid coordinate is the near plane when the ray runs up the axis (A >= 0): its offset goes down, the other one up
+    S.qb = mk3(A.x >= 0.0f ? B.x - e.x : B.x + e.x, A.y >= 0.0f ? B.y - e.y : B.y + e.y, A.z >= 0.0f ? B.z - e.z : B.z + e.z);
+    S.qc = mk3(A.x >= 0.0f ? B.x + e.x : B.x - e.x, A.y >= 0.0f ? B.y + e.y : B.y - e.y, A.z >= 0.0f ? B.z + e.z : B.z - e.z);
+    S.inv = A;
   }
   float tplane = INFINITY;
   int plane_id = -1;

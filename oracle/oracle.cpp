@@ -676,11 +676,11 @@ static inline bool hit_aabb_t(const ONode& b, const V3& o, const V3& inv, float 
 static inline uint32_t q_lo(float x, float smin, float step) { float q = floorf((x - smin) / step) - 1.0f; return (uint32_t)fminf(fmaxf(q, 0.0f), 65535.0f); }
 static inline uint32_t q_hi(float x, float smin, float step) { float q = ceilf((x - smin) / step) + 1.0f; return (uint32_t)fminf(fmaxf(q, 0.0f), 65535.0f); }
 /* box test on the quantised form of box b: plane parameter = q * A + B (one rounding), A = step * inv, B = (smin - o) * inv */
-static inline bool hit_qbox(const ONode& b, const float* smin, const float* step, const V3& A, const V3& B, float tmin, float tmax, float* te)
+static inline bool hit_qbox(const ONode& b, const float* smin, const float* step, const V3& A, const V3& Blo, const V3& Bhi, float tmin, float tmax, float* te)
 {
-  float x0 = fmaf((float)q_lo(b.xmin, smin[0], step[0]), A.x, B.x), x1 = fmaf((float)q_hi(b.xmax, smin[0], step[0]), A.x, B.x);
-  float y0 = fmaf((float)q_lo(b.ymin, smin[1], step[1]), A.y, B.y), y1 = fmaf((float)q_hi(b.ymax, smin[1], step[1]), A.y, B.y);
-  float z0 = fmaf((float)q_lo(b.zmin, smin[2], step[2]), A.z, B.z), z1 = fmaf((float)q_hi(b.zmax, smin[2], step[2]), A.z, B.z);
+  float x0 = fmaf((float)q_lo(b.xmin, smin[0], step[0]), A.x, Blo.x), x1 = fmaf((float)q_hi(b.xmax, smin[0], step[0]), A.x, Bhi.x);
+  float y0 = fmaf((float)q_lo(b.ymin, smin[1], step[1]), A.y, Blo.y), y1 = fmaf((float)q_hi(b.ymax, smin[1], step[1]), A.y, Bhi.y);
+  float z0 = fmaf((float)q_lo(b.zmin, smin[2], step[2]), A.z, Blo.z), z1 = fmaf((float)q_hi(b.zmax, smin[2], step[2]), A.z, Bhi.z);
   float t_enter = fmaxf(fmaxf(fminf(x0, x1), fminf(y0, y1)), fminf(z0, z1));
   float t_exit = fminf(fminf(fmaxf(x0, x1), fmaxf(y0, y1)), fmaxf(z0, z1));
   *te = t_enter;
@@ -710,6 +710,11 @@ static Obj traverse_ordered(Ctx& cx, const Ray& ray, float initial_t_max, bool e
   for (int k = 0; k < 3; ++k) { float range = sc.smax[k] - sc.smin[k]; qstep[k] = range > 0.0f ? range / 65535.0f : 1.0f; }
   const V3 qB = mk((sc.smin[0] - ray.eye.x) * inv.x, (sc.smin[1] - ray.eye.y) * inv.y, (sc.smin[2] - ray.eye.z) * inv.z);
   const V3 qA = mk(qstep[0] * inv.x, qstep[1] * inv.y, qstep[2] * inv.z);
+  /* the offset of the plane the ray meets first goes down, the other one up, by a bound on the rounding error of q * A + B */
+  const V3 qe = mk((fabsf(qB.x) + 65535.0f * fabsf(qA.x)) * 4.76837158203125e-07f, (fabsf(qB.y) + 65535.0f * fabsf(qA.y)) * 4.76837158203125e-07f,
+                   (fabsf(qB.z) + 65535.0f * fabsf(qA.z)) * 4.76837158203125e-07f);
+  const V3 qBlo = mk(qA.x >= 0.0f ? qB.x - qe.x : qB.x + qe.x, qA.y >= 0.0f ? qB.y - qe.y : qB.y + qe.y, qA.z >= 0.0f ? qB.z - qe.z : qB.z + qe.z);
+  const V3 qBhi = mk(qA.x >= 0.0f ? qB.x + qe.x : qB.x - qe.x, qA.y >= 0.0f ? qB.y + qe.y : qB.y - qe.y, qA.z >= 0.0f ? qB.z + qe.z : qB.z - qe.z);
   while (true) {
     const ONode& node = sc.nodes[cur];
     cx.st.node_iters++;
@@ -741,8 +746,8 @@ static Obj traverse_ordered(Ctx& cx, const Ray& ray, float initial_t_max, bool e
     cx.st.internal_visits++;
     uint32_t l = node.left, r = node.right;
     float tl, tr;
-    bool hl = qn ? hit_qbox(sc.nodes[l], sc.smin, qstep, qA, qB, tmin, tmax, &tl) : hit_aabb_t(sc.nodes[l], ray.eye, inv, tmin, tmax, &tl);
-    bool hr = qn ? hit_qbox(sc.nodes[r], sc.smin, qstep, qA, qB, tmin, tmax, &tr) : hit_aabb_t(sc.nodes[r], ray.eye, inv, tmin, tmax, &tr);
+    bool hl = qn ? hit_qbox(sc.nodes[l], sc.smin, qstep, qA, qBlo, qBhi, tmin, tmax, &tl) : hit_aabb_t(sc.nodes[l], ray.eye, inv, tmin, tmax, &tl);
+    bool hr = qn ? hit_qbox(sc.nodes[r], sc.smin, qstep, qA, qBlo, qBhi, tmin, tmax, &tr) : hit_aabb_t(sc.nodes[r], ray.eye, inv, tmin, tmax, &tr);
     if (hl && hr) {
       bool swap = false;
       if (order_pure && tr < tl) {
