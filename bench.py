@@ -269,8 +269,15 @@ def main():
                 "per_ray": {"internal_visits": cst["internal_visits"] / max(cst["rays"], 1),
                             "sphere_tests": cst["sphere_tests"] / max(cst["rays"], 1),
                             "tri_tests": cst["tri_tests"] / max(cst["rays"], 1)},
-                "note": "algorithmic bytes are delivered node bandwidth: the bundled scenes' BVH is served from L1/L2, so frac is not DRAM "
-                        "utilisation (measured_hbm_frac is); the kernel is bound by the address units and VALU issue (ta_*, valu_issue_frac)"}
+                "note": "algorithmic bytes (SURVEY.md 8d: 64 B per internal-node visit) are delivered node bandwidth: the bundled scenes' BVH "
+                        "is served from L1/L2, so frac is not DRAM utilisation (measured_hbm_frac is); the kernel is bound by VALU issue and the "
+                        "address units (valu_issue_frac, ta_*)"}
+        # what the kernel actually requests: sphere-only scenes are traversed through 32-byte quantised node records
+        qn = stl.num_triangles == 0 and stl.num_prims > 1 and raw.get_option("qnodes") and raw.get_option("traversal") >= 1 and not raw.get_option("wavefront")
+        node_bytes = 32 if qn else 64
+        roof["node_record_bytes"] = node_bytes
+        roof["requested_record_bytes_per_launch"] = int(cst["internal_visits"] * node_bytes + cst["sphere_tests"] * 16 + cst["tri_tests"] * 48 + cst["mat_fetches"] * 44)
+        roof["requested_record_GBps"] = roof["requested_record_bytes_per_launch"] / (mean_kernel_ms * 1e-3) / 1e9
         pmc = committed_pmc(workload) if world == 1 and pworld == 1 else None
         if pmc:
             name, d = pmc
