@@ -799,7 +799,8 @@ static int render_impl(MirtScene* sc, const MirtRenderParams* p, void* d_rgba8, 
       MIRT_HIP(hipMemcpyAsync(adev, &a, sizeof(RenderArgs), hipMemcpyHostToDevice, stream));
 #if MIRT_DIAG_PROF
       if (prof) {
-        hipLaunchKernelGGL((trace_kernel<false, true, 0, false>), dim3(blocks), dim3(TRACE_BLOCK), 0, stream, adev, h);
+        if (qn) hipLaunchKernelGGL((trace_kernel<false, true, 0, true>), dim3(blocks), dim3(TRACE_BLOCK), 0, stream, adev, h);
+        else hipLaunchKernelGGL((trace_kernel<false, true, 0, false>), dim3(blocks), dim3(TRACE_BLOCK), 0, stream, adev, h);
         int rc = report_prof(cx, blocks, stream);
         if (rc != MIRT_OK) return rc;
       } else
