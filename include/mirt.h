@@ -98,6 +98,8 @@ void mirt_scene_destroy(MirtScene* sc);
  *                         near-child-first at nodes whose subtrees hold spheres only -- same pixels, fewer visits;
  *                         2 near-child-first everywhere (a triangle-silhouette sample may differ where the
  *                         reference's own result depends on its visiting order)
+ *     "qnodes"            0/1 (default 1): sphere-only scenes are traversed through 32-byte quantised node records (two
+ *                         memory requests per node visit instead of four; same pixels; not with traversal 0 / wavefront)
  *     "wavefront"         0/1: the trace/shade kernel pair instead of the single kernel
  *     "slab_log2"         (default 26) a call is rendered in slabs of at most 2^slab_log2 samples: 16 B of workspace per
  *                         sample, i.e. 1 GiB, however large the frame
@@ -113,7 +115,7 @@ int mirt_scene_get_option(const MirtScene* sc, const char* name, int* value);
 
 /* build_lbvh_karas(RawConfig&, int morton_bits), lbvh_builder.cuh:14 / lbvh_builder.cu:401-521:
  * scene bounds -> 30-bit Morton codes -> stable radix sort -> Karras hierarchy -> AABB refit -> 64-byte
- * two-child node records.  Synchronous (like the reference, lbvh_builder.cu:475).  build_ms (nullable)
+ * two-child node records, primitive records in sorted order (+ 32-byte quantised node records for sphere-only scenes).  Synchronous (like the reference, lbvh_builder.cu:475).  build_ms (nullable)
  * receives the device time measured with HIP events (the reference prints it, lbvh_builder.cu:489). */
 int mirt_build_lbvh(MirtScene* sc, void* stream, float* build_ms);
 
@@ -179,9 +181,10 @@ int mirt_render_frame_multi(MirtMulti* mm, int width, int height, int spp, int s
 typedef struct MirtStats {
   /* filled by a render with MIRT_RENDER_COUNTERS */
   uint64_t samples, rays, shadow_rays, internal_visits, sphere_tests, tri_tests, mat_fetches, max_stack;
-  /* capacity overflows of the frames finished since the previous call: a traversal stack deeper than the reference's 64
-   * entries (bvh_traversal.cu:8,154-164 prints a warning and drops the subtree) or a full pending-ray list.  Always
-   * counted; when non-zero mirt_get_stats fills the struct and returns MIRT_ERR_STATE -- the image is not trustworthy. */
+  /* capacity overflows of the frames finished since the previous call: a full pending-ray list (refraction / GI children).
+   * Always counted; when non-zero mirt_get_stats fills the struct and returns MIRT_ERR_STATE -- the image is not
+   * trustworthy.  (The reference's other capacity, its 64-entry traversal stack -- bvh_traversal.cu:8,154-164 prints a
+   * warning and drops the subtree -- cannot overflow: the tree is at most 58 levels deep) */
   uint64_t overflow_events;
   /* device time of the last render's trace kernel and of the whole render call, HIP events, ms */
   float trace_kernel_ms, render_ms;
