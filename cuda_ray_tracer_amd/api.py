@@ -286,6 +286,10 @@ class MultiGpu:
         _check(lib().mirt_multi_create(C.byref(stl.desc), ngpu, dv, C.byref(h)))
         self._h = h
 
+    def set_option(self, name, value):
+        """mirt_multi_set_option: the option on every device's scene."""
+        _check(lib().mirt_multi_set_option(self._h, name.encode(), int(value)))
+
     def render_frame(self, width, height, spp, stripe_rows=4):
         import numpy as np
         out = np.zeros((height, width, 4), np.uint8)

@@ -100,6 +100,21 @@ def deep_stack(n=3000):
     return "".join(lines)
 
 
+def far_camera(n=400):
+    """A unit-sized cluster of reflective spheres over a plane, seen through a long lens from 30 000 units away: every ray
+    parameter near the cluster is ~3e4, whose ulp (0.002) is 60 grid steps of the quantised node records (2 / 65535) -- the
+    regime in which their box test has to round outwards (shade_common.h, box_pair_q)."""
+    rng = np.random.default_rng(11)
+    out = [HEADER, "bounces 3\n", "eye 0.1 0.3 30000\n", "forward 0 0 -30000\n", "color 1 1 1\n", "sun 1 1 1\n", "sun -1 2 0.5\n",
+           "color 0.6 0.6 0.6\n", "shininess 0.3\n", "plane 0 1 0 1\n", "shininess 0.5\n"]
+    for _ in range(n):
+        c = rng.uniform(-1, 1, 3)
+        col = rng.uniform(0.2, 1, 3)
+        out.append("color %.3f %.3f %.3f\n" % tuple(col))
+        out.append("sphere %.4f %.4f %.4f %.4f\n" % (c[0], c[1], c[2], rng.uniform(0.03, 0.12)))
+    return "".join(out)
+
+
 ALL = {"bulbs_and_planes": bulbs_and_planes, "fisheye": fisheye, "panorama": panorama, "empty": empty, "plane_only": plane_only,
        "single_sphere": single_sphere, "single_triangle": single_triangle, "zero_bounces": zero_bounces,
        "glass_gi_dof": one_bounce_glass_gi, "deep_stack": deep_stack}

@@ -101,8 +101,13 @@ def test_multi_gpu_entry_point_with_one_gpu_gives_the_single_gpu_frame(gpu_scene
     torch.cuda.synchronize()
     mg = api.MultiGpu(stl, 1)
     frame, st = mg.render_frame(w, h, spp)
-    mg.close()
     assert np.array_equal(frame.reshape(-1), img.cpu().numpy())
     assert st["num_gpus"] == 1 and st["render_ms"][0] > 0
+    mg.set_option("traversal", 0)                      # the reference's visiting order on every device: same bytes
+    frame0, _ = mg.render_frame(w, h, spp)
+    assert np.array_equal(frame0, frame)
+    with pytest.raises(m.MirtError):
+        mg.set_option("traversal", 7)
+    mg.close()
     with pytest.raises(m.MirtError):
         api.MultiGpu(stl, 2, devices=[0, 0])

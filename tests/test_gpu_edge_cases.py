@@ -28,7 +28,7 @@ def run_case(text, w, h, spp, **options):
     tree = raw.tree() if stl.num_prims > 0 else None
     raw.close()
     o = ol.OracleScene(pyscene.parse_lines(text.split("\n")), bounds_mode=0)
-    ref = o.render(w, h, spp, flags=ol.product_flags(stl.num_triangles > 0), nthreads=8)
+    ref = o.render(w, h, spp, flags=ol.product_flags(stl.num_triangles > 0, qnodes=options.get("qnodes", 1) != 0), nthreads=8)
     if tree is not None:
         on = o.nodes()
         for f in ("left", "right"):
@@ -62,6 +62,16 @@ def test_stack_spill_path():
     st, img = run_case(edge_scenes.deep_stack(3000), 24, 18, 4, stack_lds_depth=2)
     assert st["max_stack"] >= 10, st["max_stack"]
     run_case(edge_scenes.deep_stack(500), 16, 12, 1, stack_lds_depth=0)
+
+
+def test_quantised_nodes_are_conservative_for_far_ray_origins():
+    """Sphere-only scene, camera 30 000 scene sizes away: the quantised records give the bytes of the 64-byte float records
+    (and of the oracle), with the oracle's visit counters."""
+    text = edge_scenes.far_camera()
+    st_q, img_q = run_case(text, 96, 72, 4)                       # default: quantised nodes
+    st_f, img_f = run_case(text, 96, 72, 4, qnodes=0)
+    assert np.array_equal(img_q, img_f) and img_q[..., 3].max() == 255
+    assert st_q["rays"] == st_f["rays"] and st_q["internal_visits"] >= st_f["internal_visits"]
 
 
 def test_options_are_validated():
