@@ -46,7 +46,7 @@ constexpr int MAX_CHUNK_SHIFT = 8, MIN_CHUNK_SHIFT = 6;   // a wave takes 64..25
 #define MIRT_WAVES_PER_SIMD 4   // 128 VGPRs: measured best (2: 86 ms, 3: 76 ms, 4: 68 ms, 5: 79 ms on tenthousand 1080p16)
 #endif
 #ifndef MIRT_STACK_LDS
-#define MIRT_STACK_LDS 32
+#define MIRT_STACK_LDS 24
 #endif
 constexpr int STACK_LDS = MIRT_STACK_LDS;
 // QN: the scene's nodes are 32-byte quantised records (sphere-only scenes, scene_dev.h)
@@ -63,6 +63,9 @@ __global__ void __launch_bounds__(TRACE_BLOCK, MIRT_WAVES_PER_SIMD) trace_kernel
   // The random-number state (8 words per lane) is only touched in the shade phase: it lives here during traversal so
   // that it does not occupy registers across the hot loop (the kernel runs at the 128-VGPR edge of 4 waves per SIMD).
   __shared__ uint4 lds_rng[2][TRACE_BLOCK];
+  // Likewise eight words of shading state that the traversal loop and its batch transitions never touch (radiance so far,
+  // alpha, the diffuse weight, the node's index of refraction).
+  __shared__ uint4 lds_park[2][TRACE_BLOCK];
   uint32_t* const lds_stack = reinterpret_cast<uint32_t*>(lds_raw);
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -93,6 +96,8 @@ __global__ void __launch_bounds__(TRACE_BLOCK, MIRT_WAVES_PER_SIMD) trace_kernel
 
   lds_rng[0][tid] = make_uint4(0, 0, 0, 0);
   lds_rng[1][tid] = make_uint4(0, 0, 0, 0);
+  lds_park[0][tid] = make_uint4(0, 0, 0, 0);
+  lds_park[1][tid] = make_uint4(0, 0, 0, __float_as_uint(1.458f));
   for (;;) {
     // ================= shade / refill phase: lanes that are not traversing =================
     unsigned long long pf_a = 0;
@@ -107,6 +112,9 @@ __global__ void __launch_bounds__(TRACE_BLOCK, MIRT_WAVES_PER_SIMD) trace_kernel
       const uint4 r0 = lds_rng[0][tid], r1 = lds_rng[1][tid];
       S.rng.v0 = r0.x; S.rng.v1 = r0.y; S.rng.v2 = r0.z; S.rng.v3 = r0.w;
       S.rng.v4 = r1.x; S.rng.d = r1.y; S.rng.bm_extra = __uint_as_float(r1.z); S.rng.bm_flag = (int)r1.w;
+      const uint4 p0 = lds_park[0][tid], p1 = lds_park[1][tid];
+      S.L = mk3(__uint_as_float(p0.x), __uint_as_float(p0.y), __uint_as_float(p0.z)); S.alpha = __uint_as_float(p0.w);
+      S.wD = mk3(__uint_as_float(p1.x), __uint_as_float(p1.y), __uint_as_float(p1.z)); S.Hior = __uint_as_float(p1.w);
     }
     // (once the frame's queue is empty the first ray of a new batch is started by the traversal loop's header instead)
     while (!S.trav && S.g >= 0 && !(exhausted && S.batch_pending)) {
@@ -151,6 +159,8 @@ __global__ void __launch_bounds__(TRACE_BLOCK, MIRT_WAVES_PER_SIMD) trace_kernel
     }
     lds_rng[0][tid] = make_uint4(S.rng.v0, S.rng.v1, S.rng.v2, S.rng.v3);
     lds_rng[1][tid] = make_uint4(S.rng.v4, S.rng.d, __float_as_uint(S.rng.bm_extra), (uint32_t)S.rng.bm_flag);
+    lds_park[0][tid] = make_uint4(__float_as_uint(S.L.x), __float_as_uint(S.L.y), __float_as_uint(S.L.z), __float_as_uint(S.alpha));
+    lds_park[1][tid] = make_uint4(__float_as_uint(S.wD.x), __float_as_uint(S.wD.y), __float_as_uint(S.wD.z), __float_as_uint(S.Hior));
     if (__ballot(S.trav || S.batch_pending) == 0) {
       if (exhausted && __ballot(S.g >= 0) == 0) break;
       continue;
