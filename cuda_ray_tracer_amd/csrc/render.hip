@@ -49,10 +49,12 @@ constexpr int MAX_CHUNK_SHIFT = 8, MIN_CHUNK_SHIFT = 6;   // a wave takes 64..25
 #define MIRT_STACK_LDS 24
 #endif
 constexpr int STACK_LDS = MIRT_STACK_LDS;
-// QN: the scene's nodes are 32-byte quantised records (sphere-only scenes, scene_dev.h)
-template <bool COUNT, bool PROF, int TABLES, bool QN>
+// QN: the scene's nodes are 32-byte quantised records (sphere-only scenes, scene_dev.h); SPECX: SPEC_NOBULB / SPEC_NOPEND of
+// shade_common.h (instantiated: both or none with QN; both, SPEC_NOBULB or none without)
+template <bool COUNT, bool PROF, int TABLES, bool QN, int SPECX = 0>
 __global__ void __launch_bounds__(TRACE_BLOCK, MIRT_WAVES_PER_SIMD) trace_kernel(const RenderArgs* __restrict__ ap, const HotArgs h)
 {
+  constexpr int SPEC = (QN ? SPEC_NOTRI : 0) | SPECX;
   // PROF: diagnostic build only -- cycle stamps per phase, written to h.prof (never used for timing claims)
   unsigned long long pf_S = 0, pf_T = 0, pf_iters = 0, pf_active = 0, pf_Sent = 0, pf_Slanes = 0, pf_Bent = 0, pf_Blanes = 0, pf_leaf = 0, pf_node = 0;
   const unsigned long long pf_t0 = PROF ? clock64() : 0;
@@ -92,6 +94,7 @@ __global__ void __launch_bounds__(TRACE_BLOCK, MIRT_WAVES_PER_SIMD) trace_kernel
   S.bo = mk3(0, 0, 0); S.rdir = mk3(0, 0, 1); S.li = 0; S.occl = 0ull; S.batch_pending = false; S.has_reflect = false;
   S.o = mk3(0, 0, 0); S.d = mk3(0, 0, 1); S.inv = mk3(0, 0, 1); S.bounce = 0; S.limit = INFINITY; S.shadow = false;
   S.tplane = INFINITY; S.plane_id = -1;
+  S.qb = mk3(0, 0, 0); S.qc = mk3(0, 0, 0); S.qsx = S.qsy = S.qsz = 0;
   S.cur = REF_NONE; S.tos = REF_NONE; S.sp = 0; S.tbest = INFINITY; S.refbest = REF_NONE;
 
   lds_rng[0][tid] = make_uint4(0, 0, 0, 0);
@@ -118,8 +121,8 @@ __global__ void __launch_bounds__(TRACE_BLOCK, MIRT_WAVES_PER_SIMD) trace_kernel
     }
     // (once the frame's queue is empty the first ray of a new batch is started by the traversal loop's header instead)
     while (!S.trav && S.g >= 0 && !(exhausted && S.batch_pending)) {
-      if (S.batch_pending) batch_next<COUNT, QN>(a, S, cn);
-      else advance<COUNT, QN>(a, S, cn, gid, gthreads);
+      if (S.batch_pending) batch_next<COUNT, QN, RenderArgs, SPEC>(a, S, cn);
+      else advance<COUNT, QN, SPEC>(a, S, cn, gid, gthreads);
       if (PROF) pf_adv_it++;
     }
     if (PROF) pf_adv += clock64() - pf_a;
@@ -186,7 +189,7 @@ __global__ void __launch_bounds__(TRACE_BLOCK, MIRT_WAVES_PER_SIMD) trace_kernel
       if (bm != 0 && (__popcll(bm) >= h.batch_k || tm == 0 || drain)) {
         if (PROF) { pf_Bent++; pf_Blanes += __popcll(bm); }
         const unsigned long long pf_b0 = PROF ? clock64() : 0;
-        if (!S.trav && S.batch_pending) batch_next<COUNT, QN>(h, S, cn);
+        if (!S.trav && S.batch_pending) batch_next<COUNT, QN, HotArgs, SPEC>(h, S, cn);
         if (PROF) pf_init += 0, pf_Bcyc += clock64() - pf_b0;
       }
       if (PROF && exhausted) { pf_xit++; pf_xact += __popcll(__ballot(S.trav)); if (drain) pf_dit++; }
@@ -215,7 +218,7 @@ __global__ void __launch_bounds__(TRACE_BLOCK, MIRT_WAVES_PER_SIMD) trace_kernel
           float t = 0.0f;
           bool hit = false;
           const float4 q0 = rec[0];
-          if (S.cur & REF_TRI) {
+          if (!QN && (S.cur & REF_TRI)) {      // (quantised nodes: a sphere-only scene)
             if (COUNT) cn.tri_tests++;
             const float4 q1 = rec[1], q2 = rec[2];
             hit = triangle_hit(q0, q1, q2, S.o, S.d, t);
@@ -246,7 +249,7 @@ __global__ void __launch_bounds__(TRACE_BLOCK, MIRT_WAVES_PER_SIMD) trace_kernel
             // two 16-byte requests: twelve grid coordinates and the child references; every node of a sphere-only scene may
             // be descended near child first
             const uint4 w0 = *reinterpret_cast<const uint4*>(nrec), w1 = *reinterpret_cast<const uint4*>(nrec + 1);
-            box_pair_q(w0, w1.x, w1.y, S.inv, S.qb, S.qc, S.tbest, tmin, hl, hr, tel, ter);
+            box_pair_q(w0, w1.x, w1.y, S.inv, S.qb, S.qc, S.qsx, S.qsy, S.qsz, S.tbest, tmin, hl, hr, tel, ter);
             lref = w1.z; rref = w1.w;
             order_children(hl, hr, tel, ter, NODE_SWAP_ANY | NODE_SWAP_PURE, h.swap_mask, lref, rref);
           } else {
@@ -701,6 +704,8 @@ static int render_impl(MirtScene* sc, const MirtRenderParams* p, void* d_rgba8, 
   a.nodes = sc->nodes; a.unit_prim = sc->unit_prim; a.mats = sc->mats;
   // quantised node records: sphere-only scenes, single-kernel path, any order but the reference's own
   const bool qn = sc->root_ref_q != REF_NONE && opt.qnodes != 0 && opt.traversal >= 1 && opt.wavefront == 0;
+  // kernels specialised for what the scene does not have (SPEC_*, shade_common.h)
+  const bool nobulb = opt.specialise != 0 && sc->d.num_bulbs == 0, nopend = opt.specialise != 0 && !need_pending;
   a.root_ref = qn ? sc->root_ref_q : sc->root_ref; a.num_spheres = sc->Ns; a.num_prims = sc->N;
   a.qparams = qn ? sc->qparams : nullptr;
   a.prim_base16 = sc->prim_base / 16u;
@@ -818,11 +823,14 @@ static int render_impl(MirtScene* sc, const MirtRenderParams* p, void* d_rgba8, 
       // one instantiation per form of the random-number tables (device_common.h, xw_init) and per node format
       {
         const bool t8 = a.needs_rng && a.rng.mode == 0 && a.rng.chunk_bits == 8;
-#define MIRT_LAUNCH(C, T, Q) hipLaunchKernelGGL((trace_kernel<C, false, T, Q>), dim3(blocks), dim3(TRACE_BLOCK), 0, stream, adev, h)
-        if (count) { if (qn) { if (t8) MIRT_LAUNCH(true, 8, true); else MIRT_LAUNCH(true, 4, true); }
-                     else    { if (t8) MIRT_LAUNCH(true, 8, false); else MIRT_LAUNCH(true, 4, false); } }
-        else       { if (qn) { if (t8) MIRT_LAUNCH(false, 8, true); else MIRT_LAUNCH(false, 4, true); }
-                     else    { if (t8) MIRT_LAUNCH(false, 8, false); else MIRT_LAUNCH(false, 4, false); } }
+#define MIRT_LAUNCH(C, T, Q, P) hipLaunchKernelGGL((trace_kernel<C, false, T, Q, P>), dim3(blocks), dim3(TRACE_BLOCK), 0, stream, adev, h)
+#define MIRT_LAUNCH_T(C, Q, P) do { if (t8) MIRT_LAUNCH(C, 8, Q, P); else MIRT_LAUNCH(C, 4, Q, P); } while (0)
+#define MIRT_LAUNCH_Q(C) do { if (qn && nobulb && nopend) MIRT_LAUNCH_T(C, true, SPEC_NOBULB | SPEC_NOPEND); else if (qn) MIRT_LAUNCH_T(C, true, 0); \
+                              else if (nobulb && nopend) MIRT_LAUNCH_T(C, false, SPEC_NOBULB | SPEC_NOPEND); \
+                              else if (nobulb) MIRT_LAUNCH_T(C, false, SPEC_NOBULB); else MIRT_LAUNCH_T(C, false, 0); } while (0)
+        if (count) MIRT_LAUNCH_Q(true); else MIRT_LAUNCH_Q(false);
+#undef MIRT_LAUNCH_Q
+#undef MIRT_LAUNCH_T
 #undef MIRT_LAUNCH
       }
     }

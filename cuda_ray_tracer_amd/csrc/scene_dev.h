@@ -140,6 +140,7 @@ struct Options {
   int chunk_shift = 0;         // 0: by frame size
   int trace_waves = 0;         // 0: fill the device
   int qnodes = 1;              // sphere-only scenes: 32-byte quantised node records in the single-kernel path (traversal >= 1)
+  int specialise = 1;          // kernels compiled without what the scene does not have: point lights; transparency and gi (SPEC_*, shade_common.h)
   int sched = 1;               // longest-first chunk order measured on earlier frames
   int slab_log2 = 26;          // a call is rendered in slabs of at most 2^slab_log2 samples (1 GiB of per-sample workspace)
   int wf_pool = 1 << 21, wf_refill_k = 16;

@@ -128,28 +128,58 @@ MIRT_DEV void box_pair(const float4 q0, const float4 q1, const float4 q2, float 
 
 // The same test on a quantised node record (scene_dev.h): a box plane is grid_origin + q * grid_step, so its ray parameter is
 // q * A + B with A = grid_step * inv_dir and B = (grid_origin - origin) * inv_dir, both set up once per ray (start_ray): one
-// fused multiply-add per plane.  (A zero direction component gives NaN parameters, which fminf / fmaxf drop: the axis is then
-// ignored, a superset like the outward rounding of the boxes themselves.)
-// The two planes of an axis use separate offsets B_lo / B_hi: start_ray moves the one of the plane the ray meets first down and
-// the other one up by a bound on the rounding error of q * A + B, so that the box the kernel tests contains the grid box for
-// any ray origin, however far from the scene (origins on an infinite plane are).
-MIRT_DEV void box_pair_q(const uint4 w0, const uint32_t w4, const uint32_t w5, const f3& A, const f3& Blo, const f3& Bhi, float tbest, float tmin,
-                         bool& hl, bool& hr, float& tel, float& ter)
+// fused multiply-add per plane.
+// * No integer-to-float conversion: a byte permute puts the 16-bit coordinate into the mantissa of 2^23, giving the float
+//   f = 2^23 + q exactly, and the offset carries the -2^23 * A (start_ray).
+// * No per-axis min / max: whether the low or the high coordinate is the plane the ray meets first depends on the sign of A
+//   alone, so the permute's per-lane selector (sel: low half, or high half when A < 0) picks the near plane and
+//   sel ^ 0x0202 the far one.  Twelve permutes + twelve fused multiply-adds + two 3-way max / min per node, where the
+//   convert-and-compare form needed twelve conversions and twelve min / max more.
+// * The near planes use the offset Cn, the far planes Cf: quantised_axis moves Cn down and Cf up by a bound on every rounding
+//   error on the way, so that the box the kernel tests contains the grid box for any ray origin, however far from the scene
+//   (origins on an infinite plane are).  A zero direction component gives NaN parameters, which fminf / fmaxf drop: the axis
+//   is then ignored -- a superset, like the outward rounding of the boxes themselves.
+MIRT_DEV void box_pair_q(const uint4 w0, const uint32_t w4, const uint32_t w5, const f3& A, const f3& Cn, const f3& Cf, uint32_t sx, uint32_t sy, uint32_t sz,
+                         float tbest, float tmin, bool& hl, bool& hr, float& tel, float& ter)
 {
-  // (scalar fused multiply-adds: the packed form, v_pk_fma_f32, cost three more live registers and put spills into the loop
-  // header: 26.7 -> 28.6 ms)
-#define MIRT_QT(w, a, b0, b1, lo, hi) const float lo = __builtin_fmaf((float)((w) & 0xffffu), a, b0), hi = __builtin_fmaf((float)((w) >> 16), a, b1)
-  MIRT_QT(w0.x, A.x, Blo.x, Bhi.x, lx0, lx1); MIRT_QT(w0.y, A.y, Blo.y, Bhi.y, ly0, ly1); MIRT_QT(w0.z, A.z, Blo.z, Bhi.z, lz0, lz1);
-  MIRT_QT(w0.w, A.x, Blo.x, Bhi.x, rx0, rx1); MIRT_QT(w4, A.y, Blo.y, Bhi.y, ry0, ry1);   MIRT_QT(w5, A.z, Blo.z, Bhi.z, rz0, rz1);
-#undef MIRT_QT
-  float te = fmaxf(fmaxf(fminf(lx0, lx1), fminf(ly0, ly1)), fminf(lz0, lz1));
-  float tx = fminf(fminf(fmaxf(lx0, lx1), fmaxf(ly0, ly1)), fmaxf(lz0, lz1));
+  const uint32_t magic = 0x4b000000u;      // 2^23: v_perm_b32 takes bytes 4-7 from its first operand, 0-3 from the second
+#define MIRT_QN(w, s) __uint_as_float(__builtin_amdgcn_perm(magic, (w), (s)))
+#define MIRT_QF(w, s) __uint_as_float(__builtin_amdgcn_perm(magic, (w), (s) ^ 0x0202u))
+  const float lnx = __builtin_fmaf(MIRT_QN(w0.x, sx), A.x, Cn.x), lfx = __builtin_fmaf(MIRT_QF(w0.x, sx), A.x, Cf.x);
+  const float lny = __builtin_fmaf(MIRT_QN(w0.y, sy), A.y, Cn.y), lfy = __builtin_fmaf(MIRT_QF(w0.y, sy), A.y, Cf.y);
+  const float lnz = __builtin_fmaf(MIRT_QN(w0.z, sz), A.z, Cn.z), lfz = __builtin_fmaf(MIRT_QF(w0.z, sz), A.z, Cf.z);
+  const float rnx = __builtin_fmaf(MIRT_QN(w0.w, sx), A.x, Cn.x), rfx = __builtin_fmaf(MIRT_QF(w0.w, sx), A.x, Cf.x);
+  const float rny = __builtin_fmaf(MIRT_QN(w4, sy), A.y, Cn.y),   rfy = __builtin_fmaf(MIRT_QF(w4, sy), A.y, Cf.y);
+  const float rnz = __builtin_fmaf(MIRT_QN(w5, sz), A.z, Cn.z),   rfz = __builtin_fmaf(MIRT_QF(w5, sz), A.z, Cf.z);
+#undef MIRT_QN
+#undef MIRT_QF
+  float te = fmaxf(fmaxf(lnx, lny), lnz);
+  float tx = fminf(fminf(lfx, lfy), lfz);
   hl = te < tx && te < tbest && tx > tmin;
   tel = te;
-  te = fmaxf(fmaxf(fminf(rx0, rx1), fminf(ry0, ry1)), fminf(rz0, rz1));
-  tx = fminf(fminf(fmaxf(rx0, rx1), fmaxf(ry0, ry1)), fmaxf(rz0, rz1));
+  te = fmaxf(fmaxf(rnx, rny), rnz);
+  tx = fminf(fminf(rfx, rfy), rfz);
   hr = te < tx && te < tbest && tx > tmin;
   ter = te;
+}
+
+// One axis of a ray in the grid of the quantised node records (start_ray): A, the offsets of the near and the far plane for
+// f = 2^23 + q, and the permute selector of the near plane's half-word.  C0 = B - 2^23 A is the offset of the plain form
+// q * A + B; the margin E = 2^-20 |B| + 1.0625 |A| exceeds every rounding on the way: of A, of B and of the final fused
+// multiply-add (2^-21 (|B| + 65535 |A|) covers those with room to spare), of C0 and of C0 -+ E (each at most
+// 2^-24 |B| + |A| / 2, half an ulp of a number near 2^23 |A|).  The tested box is the grid box grown by about one more grid
+// step.  (2^23 |A| must not overflow, or a far plane at -inf would cull the box: such an axis -- a direction component
+// below 1e-25 or so -- gets NaN offsets and is ignored like a zero one.)
+MIRT_DEV void quantised_axis(float gmin, float gstep, float o, float inv, float& A, float& Cn, float& Cf, uint32_t& sel)
+{
+  const float B = (gmin - o) * inv;
+  A = gstep * inv;
+  const float hA = fabsf(A) < 1e30f ? 1.0625f * fabsf(A) : __builtin_nanf("");
+  const float E = __builtin_fmaf(fabsf(B), 9.5367431640625e-07f, hA);
+  const float C0 = __builtin_fmaf(-8388608.0f, A, B);
+  Cn = C0 - E;
+  Cf = C0 + E;
+  sel = A >= 0.0f ? 0x07060100u : 0x07060302u;
 }
 
 // A sphere reached through quantised (larger) boxes skipped part of the box test its leaf gets in the reference's walk.  For a
@@ -249,8 +279,9 @@ struct Lane {
   unsigned long long occl;     // bit i: light i is occluded
   bool batch_pending, has_reflect;
   // ray in flight
-  f3 o, d, inv;       // (with quantised nodes `inv` holds A = grid_step / d, qb / qc the offsets B_lo / B_hi of box_pair_q)
-  f3 qb, qc;
+  f3 o, d, inv;       // (with quantised nodes `inv` holds A = grid_step / d, qb / qc the near / far offsets of box_pair_q,
+  f3 qb, qc;          //  qsx.. the near-plane selectors)
+  uint32_t qsx, qsy, qsz;
   int bounce;
   float limit;        // shadow rays: occluded iff something is hit closer than this
   bool shadow;
@@ -276,14 +307,10 @@ MIRT_DEV void start_ray(const Args& a, Lane& S, Counters& cn)
     // the ray in the grid of the quantised node records (uniform values: scalar loads)
     typedef const float __attribute__((address_space(4))) * ConstF;
     const ConstF qp = (ConstF)(unsigned long long)a.qparams;
-    const f3 B = mk3((qp[0] - S.o.x) * S.inv.x, (qp[1] - S.o.y) * S.inv.y, (qp[2] - S.o.z) * S.inv.z);
-    const f3 A = mk3(qp[3] * S.inv.x, qp[4] * S.inv.y, qp[5] * S.inv.z);
-    // |q * A + B - exact| <= a few ulp of (65535 |A| + |B|): 2^-21 of it covers the roundings of A, B and the fma
-    const f3 e = mk3((fabsf(B.x) + QGRID * fabsf(A.x)) * 4.76837158203125e-07f, (fabsf(B.y) + QGRID * fabsf(A.y)) * 4.76837158203125e-07f,
-                     (fabsf(B.z) + QGRID * fabsf(A.z)) * 4.76837158203125e-07f);
-    // the low grid coordinate is the near plane when the ray runs up the axis (A >= 0): its offset goes down, the other one up
-    S.qb = mk3(A.x >= 0.0f ? B.x - e.x : B.x + e.x, A.y >= 0.0f ? B.y - e.y : B.y + e.y, A.z >= 0.0f ? B.z - e.z : B.z + e.z);
-    S.qc = mk3(A.x >= 0.0f ? B.x + e.x : B.x - e.x, A.y >= 0.0f ? B.y + e.y : B.y - e.y, A.z >= 0.0f ? B.z + e.z : B.z - e.z);
+    f3 A;
+    quantised_axis(qp[0], qp[3], S.o.x, S.inv.x, A.x, S.qb.x, S.qc.x, S.qsx);
+    quantised_axis(qp[1], qp[4], S.o.y, S.inv.y, A.y, S.qb.y, S.qc.y, S.qsy);
+    quantised_axis(qp[2], qp[5], S.o.z, S.inv.z, A.z, S.qb.z, S.qc.z, S.qsz);
     S.inv = A;
   }
   float tplane = INFINITY;
@@ -312,7 +339,14 @@ MIRT_DEV void set_ray(Lane& S, const RayS& r) { S.o = r.o; S.d = r.d; S.bounce =
 // not (draw.cu:353-357, 371-374), so its shadow ray is answered without a traversal: it still counts as a ray, and the light
 // is left "not occluded" (its term is then computed as usual and is 0).  Needs every colour of the scene to be finite
 // (0 * colour == 0; checked at scene creation) and at most 32 lights (the mask shares a word pair with the occlusion bits).
-template <typename Args>
+// Kernel specialisations by scene (template parameter SPEC of the shading functions): what a scene does not have is left out of
+// its kernel at compile time -- less code in the divergent shading phase and, above all, fewer live registers.
+//   SPEC_NOTRI   no triangles (the scenes with quantised nodes)
+//   SPEC_NOBULB  no point lights
+//   SPEC_NOPEND  no transparent material and gi 0: no refraction states, no pending-children list
+constexpr int SPEC_NOTRI = 1, SPEC_NOBULB = 2, SPEC_NOPEND = 4;
+
+template <typename Args, int SPEC = 0>
 MIRT_DEV uint32_t unlit_mask(const Args& a, const f3& pn, const f3& Hp)
 {
   uint32_t m = 0u;
@@ -321,7 +355,7 @@ MIRT_DEV uint32_t unlit_mask(const Args& a, const f3& pn, const f3& Hp)
       const LightDev& lt = a.suns[li];
       if (!(dot(pn, mk3(lt.nx, lt.ny, lt.nz)) > 0.0f)) m |= 1u << li;
     }
-    for (int li = 0; li < a.num_bulbs; ++li) {
+    if (!(SPEC & SPEC_NOBULB)) for (int li = 0; li < a.num_bulbs; ++li) {
       const LightDev& lt = a.bulbs[li];
       if (!(dot(pn, normalize(mk3(lt.x, lt.y, lt.z) - Hp)) > 0.0f)) m |= 1u << (a.num_suns + li);
     }
@@ -332,10 +366,11 @@ MIRT_DEV uint32_t unlit_mask(const Args& a, const f3& pn, const f3& Hp)
 // The ray of the batch that was in flight has finished: note a shadow result, start the next ray of the batch
 // (shadow rays of diffuseLight, draw.cu:342-374, then the reflection ray of reflectionLight, draw.cu:402-404).
 // Shadow rays consume no random numbers, so tracing them after the reflection direction was drawn changes nothing.
-template <bool COUNT, bool QN = false, typename Args = RenderArgs>
+template <bool COUNT, bool QN = false, typename Args = RenderArgs, int SPEC = 0>
 MIRT_DEV void batch_next(const Args& a, Lane& S, Counters& cn)
 {
-  const int nlights = a.num_suns + a.num_bulbs;
+  constexpr bool NOBULB = (SPEC & SPEC_NOBULB) != 0;
+  const int nlights = NOBULB ? a.num_suns : a.num_suns + a.num_bulbs;
   if (S.li >= 0 && S.li < nlights) {
     const bool occluded = (S.plane_id >= 0 && S.tplane < S.limit) || (S.refbest != REF_NONE && S.tbest < S.limit);
     if (occluded) S.occl |= 1ull << S.li;
@@ -359,7 +394,7 @@ MIRT_DEV void batch_next(const Args& a, Lane& S, Counters& cn)
     S.limit = INFINITY;
     S.shadow = true;
     S.bounce = 1;
-    if (S.li < a.num_suns) {
+    if (NOBULB || S.li < a.num_suns) {
       // direction and its reciprocal are per-light constants (host-computed, same arithmetic)
       const LightDev& lt = a.suns[S.li];
       S.d = mk3(lt.nx, lt.ny, lt.nz); S.inv = mk3(lt.ix, lt.iy, lt.iz);
@@ -388,10 +423,11 @@ MIRT_DEV void batch_next(const Args& a, Lane& S, Counters& cn)
 // sample is complete.  Returns M_DONE (sample finished: S.L / S.alpha hold the RGBA), M_BATCH (a new shading node was
 // entered: S.bo, S.rdir, S.has_reflect describe its ray batch, S.li = -1) or M_TRACE (a single ray is in S.o/S.d/S.bounce).
 // `gid`/`gthreads` address this lane's column of the pending-children LIFO (a.pending).
-template <bool COUNT>
+template <bool COUNT, int SPEC = 0>
 MIRT_DEV int advance_core(const RenderArgs& a, Lane& S, Counters& cn, const long long gid, const long long gthreads)
 {
-  const int nlights = a.num_suns + a.num_bulbs;
+  constexpr bool NOTRI = (SPEC & SPEC_NOTRI) != 0, NOBULB = (SPEC & SPEC_NOBULB) != 0, NOPEND = (SPEC & SPEC_NOPEND) != 0;
+  const int nlights = NOBULB ? a.num_suns : a.num_suns + a.num_bulbs;
   int micro = M_TRACE;
   const bool bvh_hit = S.refbest != REF_NONE;
   const bool pl_hit = S.plane_id >= 0;
@@ -402,7 +438,7 @@ MIRT_DEV int advance_core(const RenderArgs& a, Lane& S, Counters& cn, const long
     f3 Dacc = mk3(0.0f, 0.0f, 0.0f);
     for (int li = 0; li < nlights; ++li) {
       if ((S.occl >> li) & 1ull) continue;
-      if (li < a.num_suns) {
+      if (NOBULB || li < a.num_suns) {
         const LightDev& lt = a.suns[li];
         const float lambert = fmaxf(dot(S.pn, mk3(lt.nx, lt.ny, lt.nz)), 0.0f);
         const float r = S.Hcolor.x * (lt.r * lambert), gg = S.Hcolor.y * (lt.g * lambert), b = S.Hcolor.z * (lt.b * lambert);
@@ -433,7 +469,7 @@ MIRT_DEV int advance_core(const RenderArgs& a, Lane& S, Counters& cn, const long
       const float4* rec = a.nodes + off16;
       const uint32_t id = a.unit_prim[off16 - a.prim_base16] & 0x7fffffffu;
       Np = S.tbest * rd0 + ro0;
-      if (S.refbest & REF_TRI) {
+      if (!NOTRI && (S.refbest & REF_TRI)) {
         const float4 q0 = rec[0], q1 = rec[1];
         const f3 nor = mk3(q0.w, q1.x, q1.y);
         const float denom = dot(rd0, nor);
@@ -456,7 +492,7 @@ MIRT_DEV int advance_core(const RenderArgs& a, Lane& S, Counters& cn, const long
       nm = plane_mat(pl);
     }
 
-    if (S.state == ST_REFR_INSIDE) {
+    if (!NOPEND && S.state == ST_REFR_INSIDE) {
       // second half of refractionLight, draw.cu:484-493.  No miss check: a miss yields the default ObjectInfo
       // (normal 0, ior 1.458, point 0), which is what Np/Nn/nm hold then.
       const f3 normal = normalize(Nn);
@@ -476,7 +512,7 @@ MIRT_DEV int advance_core(const RenderArgs& a, Lane& S, Counters& cn, const long
       int Xbounce;
       float Xior;
       bool XtransNZ, x_parent = false, has_gi = false;
-      if (S.state == ST_PRIMARY) { S.alpha = 1.0f; S.wt = mk3(1.0f, 1.0f, 1.0f); has_gi = true; S.gi_n = a.gi; }
+      if (S.state == ST_PRIMARY) { S.alpha = 1.0f; S.wt = mk3(1.0f, 1.0f, 1.0f); has_gi = true; S.gi_n = NOPEND ? 0 : a.gi; }
       else if (S.state == ST_BATCH) x_parent = true;
       else if (S.state == ST_GI) has_gi = true;     // gi_n was set when the ray was made
       Xdir = S.Hdir; Xbounce = S.Hbounce; Xp = S.Hp; Xn = S.Hn; Xior = S.Hior; XtransNZ = S.HtransNZ;
@@ -489,6 +525,7 @@ MIRT_DEV int advance_core(const RenderArgs& a, Lane& S, Counters& cn, const long
       const f3 K = (one - Sh) * (one - T);
       // (a full pending list would drop the child: counted, and mirt_get_stats reports it as an error -- the list is sized for
       // the deepest chain the scene's bounces / gi allow, so this does not happen)
+      if (NOPEND) { has_gi = false; XtransNZ = false; }      // (gi 0 and no transparent material: nothing is ever pending)
       if (has_gi && a.gi != 0 && S.gi_n != 0 && S.pc >= a.pending_slots) atomicAdd(a.overflow, 1ull);
       if (XtransNZ && Xbounce > 0 && S.pc + ((has_gi && a.gi != 0 && S.gi_n != 0) ? 1 : 0) >= a.pending_slots) atomicAdd(a.overflow, 1ull);
       if (has_gi && a.gi != 0 && S.gi_n != 0 && S.pc < a.pending_slots) {
@@ -530,7 +567,7 @@ MIRT_DEV int advance_core(const RenderArgs& a, Lane& S, Counters& cn, const long
         S.has_reflect = (S.Hbounce - 1) != 0;      // a bounce-0 ray never hits (draw.cu:294)
       }
       S.bo = S.Hp + S.Hn * EPSILON;
-      S.occl = (unsigned long long)unlit_mask(a, S.pn, S.Hp) << 32;
+      S.occl = (unsigned long long)unlit_mask<RenderArgs, SPEC>(a, S.pn, S.Hp) << 32;
       S.li = -1;
       S.batch_pending = true;
       S.state = ST_BATCH;
@@ -541,7 +578,7 @@ MIRT_DEV int advance_core(const RenderArgs& a, Lane& S, Counters& cn, const long
   // run the micro-states until this lane has a ray or is finished
   while (micro == M_POP) {
     {
-      if (S.pc == 0) micro = M_DONE;
+      if (NOPEND || S.pc == 0) micro = M_DONE;
       else {
         --S.pc;
         const float* e = a.pending + ((size_t)S.pc * PENDING_WORDS) * gthreads + gid;
@@ -584,10 +621,10 @@ MIRT_DEV int advance_core(const RenderArgs& a, Lane& S, Counters& cn, const long
 }
 
 // Megakernel form: consume the finished trace, shade, and start the next ray of this lane (or finish the sample).
-template <bool COUNT, bool QN = false>
+template <bool COUNT, bool QN = false, int SPEC = 0>
 MIRT_DEV void advance(const RenderArgs& a, Lane& S, Counters& cn, const long long gid, const long long gthreads)
 {
-  const int micro = advance_core<COUNT>(a, S, cn, gid, gthreads);
+  const int micro = advance_core<COUNT, SPEC>(a, S, cn, gid, gthreads);
   if (micro == M_DONE) {
     a.samples[S.g] = make_float4(S.L.x, S.L.y, S.L.z, S.alpha);
     // scheduling statistic: the chunk's most expensive sample.  A plain (possibly stale, never too large) load first: most
@@ -599,7 +636,7 @@ MIRT_DEV void advance(const RenderArgs& a, Lane& S, Counters& cn, const long lon
     S.g = -1;
     S.trav = false;
   } else if (micro == M_BATCH) {
-    batch_next<COUNT, QN>(a, S, cn);
+    batch_next<COUNT, QN, RenderArgs, SPEC>(a, S, cn);
   } else {
     S.shadow = false;
     S.limit = INFINITY;

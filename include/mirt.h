@@ -100,6 +100,9 @@ void mirt_scene_destroy(MirtScene* sc);
  *                         reference's own result depends on its visiting order)
  *     "qnodes"            0/1 (default 1): sphere-only scenes are traversed through 32-byte quantised node records (two
  *                         memory requests per node visit instead of four; same pixels; not with traversal 0 / wavefront)
+ *     "specialise"        0/1 (default 1): a scene without point lights (and, sphere-only scenes, without transparent materials
+ *                         and gi) is rendered by the kernel compiled without those features (same pixels and counters;
+ *                         0: the general kernel)
  *     "wavefront"         0/1: the trace/shade kernel pair instead of the single kernel
  *     "slab_log2"         (default 26) a call is rendered in slabs of at most 2^slab_log2 samples: 16 B of workspace per
  *                         sample, i.e. 1 GiB, however large the frame

@@ -675,14 +675,36 @@ static inline bool hit_aabb_t(const ONode& b, const V3& o, const V3& inv, float 
 
 static inline uint32_t q_lo(float x, float smin, float step) { float q = floorf((x - smin) / step) - 1.0f; return (uint32_t)fminf(fmaxf(q, 0.0f), 65535.0f); }
 static inline uint32_t q_hi(float x, float smin, float step) { float q = ceilf((x - smin) / step) + 1.0f; return (uint32_t)fminf(fmaxf(q, 0.0f), 65535.0f); }
-/* box test on the quantised form of box b: plane parameter = q * A + B (one rounding), A = step * inv, B = (smin - o) * inv */
-static inline bool hit_qbox(const ONode& b, const float* smin, const float* step, const V3& A, const V3& Blo, const V3& Bhi, float tmin, float tmax, float* te)
+/* One axis of a ray in the grid of the quantised boxes, as the product sets it up (shade_common.h quantised_axis): the plane
+ * parameter is f * A + C with f = 2^23 + q (exact in float), A = step * inv, C = (smin - o) * inv - 2^23 * A -+ a margin.  The
+ * near plane (low coordinate iff A >= 0) uses Cn, the far plane Cf; the margin bounds every rounding on the way, so that the
+ * box tested contains the grid box. */
+struct QAxis { float A, Cn, Cf; bool low_near; };
+static inline QAxis quantised_axis(float gmin, float gstep, float o, float inv)
 {
-  float x0 = fmaf((float)q_lo(b.xmin, smin[0], step[0]), A.x, Blo.x), x1 = fmaf((float)q_hi(b.xmax, smin[0], step[0]), A.x, Bhi.x);
-  float y0 = fmaf((float)q_lo(b.ymin, smin[1], step[1]), A.y, Blo.y), y1 = fmaf((float)q_hi(b.ymax, smin[1], step[1]), A.y, Bhi.y);
-  float z0 = fmaf((float)q_lo(b.zmin, smin[2], step[2]), A.z, Blo.z), z1 = fmaf((float)q_hi(b.zmax, smin[2], step[2]), A.z, Bhi.z);
-  float t_enter = fmaxf(fmaxf(fminf(x0, x1), fminf(y0, y1)), fminf(z0, z1));
-  float t_exit = fminf(fminf(fmaxf(x0, x1), fmaxf(y0, y1)), fmaxf(z0, z1));
+  QAxis a;
+  const float B = (gmin - o) * inv;
+  a.A = gstep * inv;
+  const float hA = fabsf(a.A) < 1e30f ? 1.0625f * fabsf(a.A) : NAN;
+  const float E = fmaf(fabsf(B), 9.5367431640625e-07f, hA);
+  const float C0 = fmaf(-8388608.0f, a.A, B);
+  a.Cn = C0 - E;
+  a.Cf = C0 + E;
+  a.low_near = a.A >= 0.0f;
+  return a;
+}
+/* box test on the quantised form of box b */
+static inline bool hit_qbox(const ONode& b, const float* smin, const float* step, const QAxis* ax, float tmin, float tmax, float* te)
+{
+  const float lo[3] = {8388608.0f + (float)q_lo(b.xmin, smin[0], step[0]), 8388608.0f + (float)q_lo(b.ymin, smin[1], step[1]), 8388608.0f + (float)q_lo(b.zmin, smin[2], step[2])};
+  const float hi[3] = {8388608.0f + (float)q_hi(b.xmax, smin[0], step[0]), 8388608.0f + (float)q_hi(b.ymax, smin[1], step[1]), 8388608.0f + (float)q_hi(b.zmax, smin[2], step[2])};
+  float tn[3], tf[3];
+  for (int k = 0; k < 3; ++k) {
+    tn[k] = fmaf(ax[k].low_near ? lo[k] : hi[k], ax[k].A, ax[k].Cn);
+    tf[k] = fmaf(ax[k].low_near ? hi[k] : lo[k], ax[k].A, ax[k].Cf);
+  }
+  float t_enter = fmaxf(fmaxf(tn[0], tn[1]), tn[2]);
+  float t_exit = fminf(fminf(tf[0], tf[1]), tf[2]);
   *te = t_enter;
   return t_enter < t_exit && t_enter < tmax && t_exit > tmin;
 }
@@ -708,13 +730,8 @@ static Obj traverse_ordered(Ctx& cx, const Ray& ray, float initial_t_max, bool e
   const bool qn = (cx.flags & ORC_FLAG_QNODES) != 0 && N > 1;      /* (a single primitive has no node records) */
   float qstep[3];
   for (int k = 0; k < 3; ++k) { float range = sc.smax[k] - sc.smin[k]; qstep[k] = range > 0.0f ? range / 65535.0f : 1.0f; }
-  const V3 qB = mk((sc.smin[0] - ray.eye.x) * inv.x, (sc.smin[1] - ray.eye.y) * inv.y, (sc.smin[2] - ray.eye.z) * inv.z);
-  const V3 qA = mk(qstep[0] * inv.x, qstep[1] * inv.y, qstep[2] * inv.z);
-  /* the offset of the plane the ray meets first goes down, the other one up, by a bound on the rounding error of q * A + B */
-  const V3 qe = mk((fabsf(qB.x) + 65535.0f * fabsf(qA.x)) * 4.76837158203125e-07f, (fabsf(qB.y) + 65535.0f * fabsf(qA.y)) * 4.76837158203125e-07f,
-                   (fabsf(qB.z) + 65535.0f * fabsf(qA.z)) * 4.76837158203125e-07f);
-  const V3 qBlo = mk(qA.x >= 0.0f ? qB.x - qe.x : qB.x + qe.x, qA.y >= 0.0f ? qB.y - qe.y : qB.y + qe.y, qA.z >= 0.0f ? qB.z - qe.z : qB.z + qe.z);
-  const V3 qBhi = mk(qA.x >= 0.0f ? qB.x + qe.x : qB.x - qe.x, qA.y >= 0.0f ? qB.y + qe.y : qB.y - qe.y, qA.z >= 0.0f ? qB.z + qe.z : qB.z - qe.z);
+  const QAxis qax[3] = {quantised_axis(sc.smin[0], qstep[0], ray.eye.x, inv.x), quantised_axis(sc.smin[1], qstep[1], ray.eye.y, inv.y),
+                        quantised_axis(sc.smin[2], qstep[2], ray.eye.z, inv.z)};
   while (true) {
     const ONode& node = sc.nodes[cur];
     cx.st.node_iters++;
@@ -746,8 +763,8 @@ static Obj traverse_ordered(Ctx& cx, const Ray& ray, float initial_t_max, bool e
     cx.st.internal_visits++;
     uint32_t l = node.left, r = node.right;
     float tl, tr;
-    bool hl = qn ? hit_qbox(sc.nodes[l], sc.smin, qstep, qA, qBlo, qBhi, tmin, tmax, &tl) : hit_aabb_t(sc.nodes[l], ray.eye, inv, tmin, tmax, &tl);
-    bool hr = qn ? hit_qbox(sc.nodes[r], sc.smin, qstep, qA, qBlo, qBhi, tmin, tmax, &tr) : hit_aabb_t(sc.nodes[r], ray.eye, inv, tmin, tmax, &tr);
+    bool hl = qn ? hit_qbox(sc.nodes[l], sc.smin, qstep, qax, tmin, tmax, &tl) : hit_aabb_t(sc.nodes[l], ray.eye, inv, tmin, tmax, &tl);
+    bool hr = qn ? hit_qbox(sc.nodes[r], sc.smin, qstep, qax, tmin, tmax, &tr) : hit_aabb_t(sc.nodes[r], ray.eye, inv, tmin, tmax, &tr);
     if (hl && hr) {
       bool swap = false;
       if (order_pure && tr < tl) {

@@ -89,6 +89,32 @@ tri -3 -2 -1
 """
 
 
+def glass_spheres_bulb():
+    """Spheres only, but with a point light, glass and gi: quantised nodes with the general (unspecialised) kernel."""
+    return HEADER + """bounces 4
+gi 1
+color 1 1 1
+sun 1 1 0.5
+color 1 0.8 0.6
+bulb 0.5 2 0
+color 0.4 0.4 0.4
+plane 0 1 0 1
+color 1 1 1
+transparency 0.8
+shininess 0.1
+ior 1.4
+sphere 0 0 -2 0.7
+transparency 0
+shininess 0.5
+roughness 0.1
+color 0.9 0.4 0.1
+sphere 1.2 0 -2.5 0.5
+color 0.2 0.9 0.3
+shininess 0
+sphere -1.1 -0.3 -1.8 0.4
+"""
+
+
 def deep_stack(n=3000):
     """n concentric, slightly shifted spheres: every box overlaps every other, so rays push at every level of a tree that
     the duplicate-code tie-break makes deep; exercises stack depths beyond the LDS part of the traversal stack."""
@@ -117,4 +143,4 @@ def far_camera(n=400):
 
 ALL = {"bulbs_and_planes": bulbs_and_planes, "fisheye": fisheye, "panorama": panorama, "empty": empty, "plane_only": plane_only,
        "single_sphere": single_sphere, "single_triangle": single_triangle, "zero_bounces": zero_bounces,
-       "glass_gi_dof": one_bounce_glass_gi, "deep_stack": deep_stack}
+       "glass_gi_dof": one_bounce_glass_gi, "glass_spheres_bulb": glass_spheres_bulb, "deep_stack": deep_stack}

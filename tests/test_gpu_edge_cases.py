@@ -74,6 +74,13 @@ def test_quantised_nodes_are_conservative_for_far_ray_origins():
     assert st_q["rays"] == st_f["rays"] and st_q["internal_visits"] >= st_f["internal_visits"]
 
 
+@pytest.mark.parametrize("name", ["fisheye", "single_triangle", "glass_gi_dof"])
+def test_general_kernels_on_scenes_that_have_specialised_ones(name):
+    """specialise = 0: the kernels compiled with every feature render the scenes that by default get a kernel without point
+    lights / transparency / gi (render.hip, SPEC_*): same oracle pixels and counters."""
+    run_case(edge_scenes.ALL[name](), 64, 48, 4, specialise=0)
+
+
 def test_options_are_validated():
     stl = m.parseText(edge_scenes.single_sphere())
     raw = m.initRawConfigFromStl(stl, 0)

@@ -19,25 +19,37 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."
 from cuda_ray_tracer_amd import build as B   # noqa: E402
 
 
-def analyze(defines=(), kernel="trace_kernelILb0ELb0ELi8ELb1E"):
+_COMPILED = {}
+
+
+def _compile(defines):
+    """render.hip -> (resource-usage remarks, gfx950 assembly); one compilation per set of defines and process."""
+    if defines not in _COMPILED:
+        out = os.path.join(tempfile.gettempdir(), "mirt_hotloop.s")
+        cmd = [B._hipcc()] + [c for c in B.COMMON if c != "-fPIC"] + list(defines) + ["-x", "hip", "-S", "--cuda-device-only", os.path.join(B.CSRC, "render.hip"),
+                                                                                   "-o", out, "-Rpass-analysis=kernel-resource-usage"]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(r.stderr[-2000:])
+        _COMPILED[defines] = (r.stderr, open(out).read())
+    return _COMPILED[defines]
+
+
+def analyze(defines=(), kernel="trace_kernelILb0ELb0ELi8ELb1ELi6EE"):
     """Returns (resources, counts, spills): the kernel's resource usage lines, instruction counts by class inside the
     traversal loop, and [(position, instruction)] of every spill instruction in it.  `kernel`: the mangled instantiation,
-    trace_kernel<COUNT, PROF, TABLES, QN>: ...Li8ELb1E = byte-indexed RNG tables, quantised nodes (the headline scene's
-    kernel); ...Li8ELb0E = 64-byte node records (scenes with triangles)."""
-    out = os.path.join(tempfile.gettempdir(), "mirt_hotloop.s")
-    cmd = [B._hipcc()] + [c for c in B.COMMON if c != "-fPIC"] + list(defines) + ["-x", "hip", "-S", "--cuda-device-only", os.path.join(B.CSRC, "render.hip"),
-                                                                               "-o", out, "-Rpass-analysis=kernel-resource-usage"]
-    r = subprocess.run(cmd, capture_output=True, text=True)
-    if r.returncode != 0:
-        raise RuntimeError(r.stderr[-2000:])
+    trace_kernel<COUNT, PROF, TABLES, QN, SPECX>: ...Li8ELb1ELi6EE = byte-indexed RNG tables, quantised nodes, no point lights /
+    transparency / gi (the headline scene's kernel); ...Li8ELb0ELi2EE = 64-byte node records (scenes with triangles), no point
+    lights (redchair.txt); ...Li0EE: the general kernels."""
+    remarks, asm = _compile(tuple(defines))
     res, want = [], False
-    for line in r.stderr.splitlines():
+    for line in remarks.splitlines():
         if "Function Name" in line:
             want = kernel in line
         elif want and re.search(r"VGPRs:|SGPRs:|Spill|ScratchSize|Occupancy", line):
             res.append(line.split("remark:")[1].rsplit("[-Rpass", 1)[0].strip())
     body, inside = [], False
-    for l in open(out).read().splitlines():
+    for l in asm.splitlines():
         if re.match(r"^_ZN4mirt.*" + kernel + r".*:", l):
             inside = True
             continue

@@ -32,7 +32,11 @@ GROUPS = {
     "sq": "SQ_INSTS_VALU SQ_INSTS_SALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_BUSY_CYCLES",
     "fetch": "FETCH_SIZE",
     "write": "WRITE_SIZE",
+    # (not in the default set) instruction cache and instruction mix
+    "icache": "SQC_ICACHE_REQ SQC_ICACHE_HITS SQC_ICACHE_MISSES SQ_IFETCH",
+    "mix": "SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS SQ_INSTS_SMEM SQ_INSTS_BRANCH SQ_INST_CYCLES_SALU",
 }
+DEFAULT_GROUPS = "ta,l1,l2,sq,fetch,write"
 CLOCK_HZ = 2.4e9
 CUS = 256
 XCDS = 8          # GRBM_GUI_ACTIVE is summed over the eight XCDs: cycles of the launch = sum / 8
@@ -47,7 +51,7 @@ def main():
     ap.add_argument("--spp", type=int, default=16)
     ap.add_argument("--tag", default="r02")
     ap.add_argument("--env", action="append", default=[])
-    ap.add_argument("--groups", default=",".join(GROUPS))
+    ap.add_argument("--groups", default=DEFAULT_GROUPS)
     ap.add_argument("--kernel", default="trace_kernel")
     args = ap.parse_args()
 
