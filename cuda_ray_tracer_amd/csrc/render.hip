@@ -726,7 +726,7 @@ static int render_impl(MirtScene* sc, const MirtRenderParams* p, void* d_rgba8, 
   a.counters = count ? cx.counters : nullptr;
   a.overflow = cx.counters + 9;
   a.lds_depth = (opt.stack_lds_depth >= 0 && opt.stack_lds_depth <= STACK_LDS) ? opt.stack_lds_depth : STACK_LDS;   // tests force the spill path
-  a.refill_k = opt.refill_k > 0 ? opt.refill_k : (qn ? 40 : 44);
+  a.refill_k = opt.refill_k > 0 ? opt.refill_k : (qn ? 32 : 44);
   a.drain_lanes = opt.drain_lanes;
   a.batch_k = opt.batch_k;
 

@@ -134,8 +134,9 @@ struct Options {
   int traversal = 1;           // MIRT_TRAVERSAL_*: 0 reference (left first), 1 ordered where pixels cannot change, 2 ordered everywhere
   int wavefront = 0;           // 1: the trace / shade kernel pair instead of the single kernel
   int stack_lds_depth = -1;    // traversal-stack entries kept in LDS (-1: the compiled size); tests force the spill path with it
-  int refill_k = 0;            // leave the traversal loop when this many lanes wait to shade; 0 = 40 with quantised nodes (sphere-only scenes:
-                               // tenthousand 27.2 / spiral 69.3 ms against 27.4 / 70.3 at 44), 44 otherwise (redchair 33.0 against 33.6 at 40)
+  int refill_k = 0;            // leave the traversal loop when this many lanes wait to shade; 0 = 32 with quantised nodes (sphere-only scenes:
+                               // tenthousand 23.9 / spiral 61.2 ms against 24.0 / 62.6 at 40 and 24.4 / 60.7 at 28), 44 otherwise (redchair 28.9
+                               // against 29.2 at 40)
   int batch_k = 8, leaf_k = 8, reps = 4, drain_lanes = 16;
   int chunk_shift = 0;         // 0: by frame size
   int trace_waves = 0;         // 0: fill the device

@@ -135,6 +135,8 @@ MIRT_DEV void box_pair(const float4 q0, const float4 q1, const float4 q2, float 
 //   alone, so the permute's per-lane selector (sel: low half, or high half when A < 0) picks the near plane and
 //   sel ^ 0x0202 the far one.  Twelve permutes + twelve fused multiply-adds + two 3-way max / min per node, where the
 //   convert-and-compare form needed twelve conversions and twelve min / max more.
+// * (The packed form of the multiply-adds, v_pk_fma_f32 on the two boxes' planes of one kind, needs its operands in register
+//   pairs: the moves eat the saving and push spills into the loop, measured twice.)
 // * The near planes use the offset Cn, the far planes Cf: quantised_axis moves Cn down and Cf up by a bound on every rounding
 //   error on the way, so that the box the kernel tests contains the grid box for any ray origin, however far from the scene
 //   (origins on an infinite plane are).  A zero direction component gives NaN parameters, which fminf / fmaxf drop: the axis
