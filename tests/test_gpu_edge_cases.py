@@ -56,7 +56,7 @@ def test_edge_scene_matches_oracle(name, spp):
 
 
 def test_stack_spill_path():
-    """Stack depths beyond 32 LDS entries + the top-of-stack register need > 2^33 overlapping primitives in a balanced
+    """Stack depths beyond 24 LDS entries + the top-of-stack register need > 2^25 overlapping primitives in a balanced
     Karras tree, so the spill path is forced instead: with the option stack_lds_depth = 2 every entry below the top three
     goes to the global spill area (max depth on this scene: 12).  Results and counters must not change."""
     st, img = run_case(edge_scenes.deep_stack(3000), 24, 18, 4, stack_lds_depth=2)

@@ -96,7 +96,7 @@ def main():
         print(f"group {g}: rc={p.returncode} " + " ".join(f"{k}={raw[k]:.5g}" for k in agg), flush=True)
 
     out = {"workload": f"{args.scene}.txt {args.width}x{args.height} {args.spp}spp", "kernel": args.kernel, "tag": args.tag,
-           "command": "rocprofv3 --pmc <group> --output-format csv -- python3 bench.py --steps 3 --warmup 1 --cpu-step 0 --serial --headline-only (one pass per group)",
+           "command": "rocprofv3 --pmc <group> --output-format csv -- python3 " + " ".join(["bench.py"] + bench[2:]) + " (one pass per group)",
            "env": args.env, "per_launch": raw, "launches_averaged": launches, "kernel_ms_under_pmc": kernel_ms, "derived": {}}
     dv = out["derived"]
     g = raw.get("GRBM_GUI_ACTIVE")
