@@ -312,11 +312,18 @@ def main():
             "roofline": roof,
         }
         if world > 1:
-            out["multi_gpu"] = {"backend": backend, "rccl_ranks": dist.get_world_size(),
+            out["multi_gpu"] = {"backend": backend, ("ranks" if rehearse else "rccl_ranks"): dist.get_world_size(),
+                                "physical_gpus": 1 if rehearse else world,
                                 "per_rank_render_ms": [float(t[0]) for t in all_ms], "per_rank_gather_ms": [float(t[1]) for t in all_ms],
                                 "per_rank_trace_kernel_ms": [float(t[2]) for t in all_ms],
                                 "note": "render = this rank's part (device time on its stream); gather = from the end of its render to the end of "
                                         "the framebuffer gather (+ re-interleave on rank 0), i.e. it includes waiting for the slowest rank"}
+        if rehearse:
+            # never to be read as a multi-GPU measurement: the ranks time-share ONE device
+            out["n_gpus"] = 1
+            out["rehearsal"] = (f"MIRT_BENCH_REHEARSE=1: {world} ranks share GPU 0 and gather over gloo -- exercises the N > 1 code path "
+                                "end to end; value / ms_per_step say nothing about scaling")
+            out["config"]["parallelism"] = f"REHEARSAL: image stripes x{world} ranks on one GPU (gloo)"
         if world == 1 and pworld == 1 and not args.headline_only and (args.scene, W, H, SPP) == HEADLINE:
             # the other BASELINE configurations on this GPU (a few frames each, serial)
             extra = []
