@@ -73,8 +73,10 @@ __global__ void __launch_bounds__(TRACE_BLOCK, MIRT_WAVES_PER_SIMD) trace_kernel
   const int lane = tid & 63;
   (void)lane;
   const unsigned char* const heap = reinterpret_cast<const unsigned char*>(h.nodes);
-  const long long gid = (long long)blockIdx.x * TRACE_BLOCK + tid;
-  const long long gthreads = (long long)gridDim.x * TRACE_BLOCK;
+  // (32-bit: the grid has far fewer than 2^31 threads; the 64-bit products below are formed where they are used)
+  const uint32_t gid32 = blockIdx.x * (uint32_t)TRACE_BLOCK + (uint32_t)tid;
+  const long long gid = (long long)gid32;
+  const long long gthreads = (long long)(gridDim.x * (uint32_t)TRACE_BLOCK);
   Counters cn = {0, 0, 0, 0, 0, 0, 0, 0};
 
   // Work distribution: the sample range is cut into chunks of 2^chunk_shift consecutive samples (16 pixels at 16 spp); a wave

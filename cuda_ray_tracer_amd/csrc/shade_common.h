@@ -263,7 +263,7 @@ struct Counters { uint32_t samples, rays, shadow_rays, internal_visits, sphere_t
 // Everything a lane carries from one loop iteration to the next.
 struct Lane {
   // sample being evaluated (g < 0: none)
-  long long g;
+  int g;              // index of the sample within this launch (a launch has < 2^31 samples: render_impl), -1: none
   Xorwow rng;
   f3 L;
   float alpha;
@@ -665,7 +665,7 @@ MIRT_DEV void init_sample_core(const RenderArgs& a, Lane& S, Counters& cn, const
   const int py = (int)(gs * (uint32_t)a.stripe_rows + wy);
   const int px = (int)(within - wy * (uint32_t)a.width);
   const uint32_t pixel = (uint32_t)py * (uint32_t)a.width + (uint32_t)px;
-  S.g = idx;
+  S.g = (int)idx;
   S.steps = 0;
   S.L = mk3(0.0f, 0.0f, 0.0f);
   S.alpha = 0.0f;

@@ -73,7 +73,7 @@ MIRT_DEV f3 ld_f3(const uint32_t* st, int pool, int slot, int w)
 
 MIRT_DEV void load_slot(const uint32_t* st, int pool, int slot, Lane& S)
 {
-  S.g = (long long)(((unsigned long long)WF_LD(W_G_HI) << 32) | WF_LD(W_G_LO));
+  S.g = (int)WF_LD(W_G_LO);      // (the high word is its sign extension)
   S.rng.v0 = WF_LD(W_RNG0); S.rng.v1 = WF_LD(W_RNG1); S.rng.v2 = WF_LD(W_RNG2); S.rng.v3 = WF_LD(W_RNG3); S.rng.v4 = WF_LD(W_RNG4);
   S.rng.d = WF_LD(W_RNGD); S.rng.bm_flag = (int)WF_LD(W_BMFLAG); S.rng.bm_extra = __uint_as_float(WF_LD(W_BMEXTRA));
   S.L = ld_f3(st, pool, slot, W_LX); S.alpha = __uint_as_float(WF_LD(W_ALPHA));
@@ -92,7 +92,7 @@ MIRT_DEV void load_slot(const uint32_t* st, int pool, int slot, Lane& S)
 
 MIRT_DEV void store_slot(uint32_t* st, int pool, int slot, const Lane& S)
 {
-  WF_ST(W_G_LO, (uint32_t)(unsigned long long)S.g); WF_ST(W_G_HI, (uint32_t)((unsigned long long)S.g >> 32));
+  WF_ST(W_G_LO, (uint32_t)S.g); WF_ST(W_G_HI, S.g < 0 ? 0xffffffffu : 0u);
   if (S.g < 0) return;
   WF_ST(W_RNG0, S.rng.v0); WF_ST(W_RNG1, S.rng.v1); WF_ST(W_RNG2, S.rng.v2); WF_ST(W_RNG3, S.rng.v3); WF_ST(W_RNG4, S.rng.v4);
   WF_ST(W_RNGD, S.rng.d); WF_ST(W_BMFLAG, (uint32_t)S.rng.bm_flag); WF_ST(W_BMEXTRA, __float_as_uint(S.rng.bm_extra));

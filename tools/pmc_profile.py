@@ -35,6 +35,7 @@ GROUPS = {
     # (not in the default set) instruction cache and instruction mix
     "icache": "SQC_ICACHE_REQ SQC_ICACHE_HITS SQC_ICACHE_MISSES SQ_IFETCH",
     "mix": "SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS SQ_INSTS_SMEM SQ_INSTS_BRANCH SQ_INST_CYCLES_SALU",
+    "wrreq": "TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum",      # write requests L2 -> memory, and how many of them are 64-byte ones
 }
 DEFAULT_GROUPS = "ta,l1,l2,sq,fetch,write"
 CLOCK_HZ = 2.4e9
