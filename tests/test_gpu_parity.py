@@ -307,6 +307,23 @@ def test_default_traversal_gives_the_bytes_of_the_reference_order(name, gpu_scen
         assert sa["internal_visits"] < 0.85 * sb["internal_visits"]
 
 
+@pytest.mark.parametrize("name", ["tenthousand", "spiral", "redchair"])
+def test_specialised_kernels_give_the_bytes_and_counters_of_the_general_ones(name, gpu_scenes):
+    """render.hip compiles the trace kernel without what a scene does not have (triangles, point lights, the pending list of
+    refraction / gi; option `specialise`).  Whole 1920x1080 x 16 spp frames: the general kernel (specialise = 0) gives the same
+    bytes, float image included, and the same value of every counter."""
+    stl, raw = gpu_scenes(name)
+    w, h, spp = 1920, 1080, 16
+    a8, af = gpu_render(raw, w, h, spp, counters=True)
+    sa = raw.stats()
+    with options(raw, specialise=0):
+        b8, bf = gpu_render(raw, w, h, spp, counters=True)
+        sb = raw.stats()
+    assert np.array_equal(a8, b8) and np.array_equal(af.view(np.uint32), bf.view(np.uint32))
+    for k in COUNTER_KEYS:
+        assert sa[k] == sb[k], (k, sa[k], sb[k])
+
+
 def test_shipped_tree_mode_reproduces_the_survey_golden_image(gpu_scenes, oracle_scenes):
     """Build option bounds_as_shipped: the reference as shipped never stores its scene bounds (parse.cpp:28), so every
     Morton code is 0.  With it, and the reference's traversal order, the HIP path itself reproduces the RNG-free known
