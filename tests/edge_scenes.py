@@ -141,6 +141,22 @@ def far_camera(n=400):
     return "".join(out)
 
 
+def axis_parallel_rays(n=6):
+    """An n x n x n lattice of spheres around the camera, which sits inside the scene's bounds and looks straight down -z: at
+    spp 0 and an even frame size the central column and row of pixels have direction components that are exactly 0 (reciprocal
+    +inf, grid parameters inf / NaN in the quantised box test, shade_common.h quantised_axis), and many rays run exactly along
+    lattice planes, i.e. along faces of node boxes."""
+    out = [HEADER, "bounces 3\n", "eye 0.5 0.5 0.5\n", "color 1 1 1\n", "sun 1 2 3\n", "sun -2 1 0\n", "shininess 0.4\n"]
+    for i in range(-n // 2, n // 2 + 1):
+        for j in range(-n // 2, n // 2 + 1):
+            for k in range(-n // 2, n // 2 + 1):
+                if (i, j, k) == (0, 0, 0):
+                    continue
+                out.append("color %.2f %.2f %.2f\n" % (0.3 + 0.1 * (i % 5), 0.3 + 0.1 * (j % 5), 0.3 + 0.1 * (k % 5)))
+                out.append("sphere %d %d %d 0.25\n" % (i, j, k))
+    return "".join(out)
+
+
 ALL = {"bulbs_and_planes": bulbs_and_planes, "fisheye": fisheye, "panorama": panorama, "empty": empty, "plane_only": plane_only,
        "single_sphere": single_sphere, "single_triangle": single_triangle, "zero_bounces": zero_bounces,
-       "glass_gi_dof": one_bounce_glass_gi, "glass_spheres_bulb": glass_spheres_bulb, "deep_stack": deep_stack}
+       "glass_gi_dof": one_bounce_glass_gi, "glass_spheres_bulb": glass_spheres_bulb, "axis_parallel_rays": axis_parallel_rays, "deep_stack": deep_stack}

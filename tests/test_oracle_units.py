@@ -172,6 +172,42 @@ def test_any_hit_shadow_rays_give_the_same_image(name, spp, oracle_scenes):
     assert b["stats"]["internal_visits"] < a["stats"]["internal_visits"]
 
 
+@pytest.mark.parametrize("name,w,h,spp", [("tenthousand", 64, 36, 16), ("spiral", 64, 36, 4), ("redchair", 48, 27, 32), ("tri", 128, 128, 0)])
+def test_the_mirror_of_the_products_default_mode_gives_the_image_of_the_reference_walk(name, w, h, spp, oracle_scenes):
+    """The link between the two halves of the parity chain.  GPU tests compare libmirt with the oracle run under the flags that
+    mirror the product's default mode (any-hit shadow rays, unlit shadow rays skipped, near child first where it cannot change
+    the hit, quantised boxes on sphere-only scenes).  Here that mirror is compared with the oracle's plain restatement of the
+    reference (flags = 0: left-first walk, every shadow ray traced to its nearest hit): same float image bit for bit, same
+    rays, fewer node visits."""
+    o = oracle_scenes(name)
+    plain = o.render(w, h, spp, flags=0, nthreads=8)
+    mirror = o.render(w, h, spp, flags=ol.product_flags(name in ("redchair", "tri")), nthreads=8)
+    assert np.array_equal(plain["f32"].view(np.uint32), mirror["f32"].view(np.uint32))
+    assert np.array_equal(plain["u8"], mirror["u8"])
+    assert plain["stats"]["rays"] == mirror["stats"]["rays"]
+    assert mirror["stats"]["internal_visits"] <= plain["stats"]["internal_visits"]
+
+
+@pytest.mark.parametrize("scene", ["bulbs_and_planes", "fisheye", "panorama", "glass_gi_dof", "glass_spheres_bulb", "axis_parallel_rays", "far_camera"])
+@pytest.mark.parametrize("spp", [0, 4])
+def test_the_mirror_equals_the_reference_walk_on_the_edge_scenes(scene, spp):
+    """The same on the synthetic edge cases: point lights, glass + gi, rays with zero direction components inside the scene's
+    bounds, a camera 30 000 scene sizes away."""
+    import edge_scenes
+    import pyscene
+    text = edge_scenes.far_camera() if scene == "far_camera" else edge_scenes.ALL[scene]()
+    sc = pyscene.parse_lines(text.split("\n"))
+    o = ol.OracleScene(sc, bounds_mode=0)
+    w, h = 64, 48
+    plain = o.render(w, h, spp, flags=0, nthreads=8)
+    mirror = o.render(w, h, spp, flags=ol.product_flags(any(l.startswith("tri ") for l in text.split("\n"))), nthreads=8)
+    o.close()
+    both_nan = np.isnan(plain["f32"]) & np.isnan(mirror["f32"])
+    assert np.array_equal(np.where(both_nan, 0, plain["f32"].view(np.uint32)), np.where(both_nan, 0, mirror["f32"].view(np.uint32)))
+    assert np.array_equal(plain["u8"], mirror["u8"])
+    assert plain["stats"]["rays"] == mirror["stats"]["rays"]
+
+
 def test_tiles_and_threads_do_not_change_pixels(oracle_scenes):
     o = oracle_scenes("tenthousand")
     whole = o.render(50, 30, 16, nthreads=1)["f32"]
