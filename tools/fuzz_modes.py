@@ -5,7 +5,7 @@ records): the frames must be identical byte for byte, float image included, with
 
     python tools/fuzz_modes.py [--scenes 200] [--seed 1]
 
-Scales from 1e-3 to 1e6, cameras inside, outside and far away from the scene, pinhole / fisheye / panorama, overlapping and
+`--triangles F` adds F triangles per sphere (mixed scenes: only sphere-only subtrees may be reordered).  Scales from 1e-3 to 1e6, cameras inside, outside and far away from the scene, pinhole / fisheye / panorama, overlapping and
 nested spheres, point lights, glass and gi in a part of the scenes (those run the general kernels).  Prints one line per
 mismatch and a summary; exit status 1 on any mismatch."""
 import argparse
@@ -20,7 +20,7 @@ import cuda_ray_tracer_amd as m          # noqa: E402
 from cuda_ray_tracer_amd import api      # noqa: E402
 
 
-def scene_text(rng):
+def scene_text(rng, tri_fraction=0.0):
     scale = 10.0 ** rng.uniform(-3, 6)
     n = int(10 ** rng.uniform(0.3, 3.7))
     lines = ["png 64 64 fuzz.png", "bounces %d" % rng.integers(1, 8)]
@@ -70,6 +70,19 @@ def scene_text(rng):
         if rng.random() < 0.05:
             r = scale * 3.0             # a big sphere that contains many others
         lines.append("sphere %.9g %.9g %.9g %.9g" % (c[0], c[1], c[2], r))
+    if tri_fraction > 0:
+        # triangles among the spheres: the tree then has subtrees that must keep the reference's order
+        for _ in range(int(n * tri_fraction) + 1):
+            if rng.random() < 0.3:
+                lines.append("color %.3f %.3f %.3f" % tuple(rng.uniform(0.1, 1.0, 3)))
+            c = rng.normal(size=3) * scale
+            size = scale * 10.0 ** rng.uniform(-2.0, 0.0)
+            for _k in range(3):
+                v = c + rng.normal(size=3) * size
+                if rng.random() < 0.2:
+                    v[rng.integers(0, 3)] = c[0]          # axis-aligned edges and flat boxes now and then
+                lines.append("xyz %.9g %.9g %.9g" % tuple(v))
+            lines.append("tri -3 -2 -1")
     return "\n".join(lines) + "\n"
 
 
@@ -87,12 +100,13 @@ def main(argv=None):
     ap.add_argument("--scenes", type=int, default=200)
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--out", default="gpurun_out", help="where the scene text of a mismatch is written")
+    ap.add_argument("--triangles", type=float, default=0.0, help="triangles per sphere added to every scene (mixed scenes: float node records)")
     args = ap.parse_args(argv)
     rng = np.random.default_rng(args.seed)
     bad = 0
     visits = [0, 0]
     for i in range(args.scenes):
-        text = scene_text(rng)
+        text = scene_text(rng, args.triangles)
         w, h, spp = 192, 108, int(rng.choice([0, 1, 2, 4]))
         stl = m.parseText(text)
         raw = m.initRawConfigFromStl(stl, 0)
