@@ -81,6 +81,25 @@ def test_general_kernels_on_scenes_that_have_specialised_ones(name):
     run_case(edge_scenes.ALL[name](), 64, 48, 4, specialise=0)
 
 
+@pytest.mark.parametrize("seed,triangles", [(31, 0.0), (32, 0.0), (33, 1.0)])
+def test_random_scenes_match_the_oracle_with_equal_counters(seed, triangles):
+    """25 random scenes per seed from tools/fuzz_modes.py's generator (scales 1e-3 .. 1e6, cameras inside / outside / far away,
+    fisheye / panorama, depth of field, some with point lights, glass and gi; seed 33: with triangles): colours within 1e-4 of
+    the oracle's, 8-bit image within one level, the tree's child links and every ray / node / leaf counter equal."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import fuzz_modes
+    rng = np.random.default_rng(seed)
+    for i in range(25):
+        text = fuzz_modes.scene_text(rng, triangles)
+        spp = int(rng.choice([0, 1, 3]))
+        try:
+            run_case(text, 48, 32, spp)
+        except AssertionError as e:
+            raise AssertionError(f"scene {i} of seed {seed} (spp {spp}): {e}") from e
+
+
 def test_options_are_validated():
     stl = m.parseText(edge_scenes.single_sphere())
     raw = m.initRawConfigFromStl(stl, 0)
