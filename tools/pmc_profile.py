@@ -54,6 +54,8 @@ def main():
     ap.add_argument("--env", action="append", default=[])
     ap.add_argument("--groups", default=DEFAULT_GROUPS)
     ap.add_argument("--kernel", default="trace_kernel")
+    ap.add_argument("--program", nargs="+", default=None, help="profile `python3 PROGRAM ARGS...` instead of bench.py (it prints one JSON line with roofline.kernel_ms)")
+    ap.add_argument("--label", default=None, help="workload label of the output (with --program)")
     args = ap.parse_args()
 
     env = dict(os.environ)
@@ -66,6 +68,10 @@ def main():
     os.makedirs(scratch, exist_ok=True)
     bench = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1", "--cpu-step", "0", "--serial", "--headline-only",
              "--scene", args.scene, "--width", str(args.width), "--height", str(args.height), "--spp", str(args.spp)]
+    workload = f"{args.scene}.txt {args.width}x{args.height} {args.spp}spp"
+    if args.program:
+        bench = [sys.executable, os.path.join(ROOT, args.program[0])] + args.program[1:]
+        workload = args.label or " ".join(args.program)
     raw = {}
     launches = {}
     kernel_ms = None
@@ -96,8 +102,8 @@ def main():
             launches[k] = len(v)
         print(f"group {g}: rc={p.returncode} " + " ".join(f"{k}={raw[k]:.5g}" for k in agg), flush=True)
 
-    out = {"workload": f"{args.scene}.txt {args.width}x{args.height} {args.spp}spp", "kernel": args.kernel, "tag": args.tag,
-           "command": "rocprofv3 --pmc <group> --output-format csv -- python3 " + " ".join(["bench.py"] + bench[2:]) + " (one pass per group)",
+    out = {"workload": workload, "kernel": args.kernel, "tag": args.tag,
+           "command": "rocprofv3 --pmc <group> --output-format csv -- python3 " + " ".join([os.path.relpath(bench[1], ROOT)] + bench[2:]) + " (one pass per group)",
            "env": args.env, "per_launch": raw, "launches_averaged": launches, "kernel_ms_under_pmc": kernel_ms, "derived": {}}
     dv = out["derived"]
     g = raw.get("GRBM_GUI_ACTIVE")
