@@ -58,6 +58,27 @@ def committed_pmc(workload):
     return best
 
 
+def committed_limiter(workload):
+    """What bounds the kernel on `workload`, from its committed counter passes (None when there are none): per launch of the
+    trace kernel (one slab of a frame that takes several)."""
+    got = committed_pmc(workload)
+    if not got:
+        return None
+    name, d = got
+    dv = d.get("derived", {})
+    # (per-launch duration from the launch's own cycle counter: a frame of several slabs is several launches)
+    launch_ms = dv.get("gui_active_ms")
+    out = {"pmc_source": "profiles/" + name, "pmc_workload": d.get("workload"), "pmc_launch_ms": launch_ms}
+    for k_out, k_in in (("valu_issue_frac", "valu_issue_frac"), ("ta_busy", "ta_busy"), ("l1_hit_rate", "l1_hit_rate"), ("l2_hit_rate", "l2_hit_rate"),
+                        ("active_lanes_per_valu_inst", "active_lanes"), ("beyond_l2_bytes_per_launch", "hbm_bytes_per_launch")):
+        if k_in in dv:
+            out[k_out] = dv[k_in]
+    if "hbm_bytes_per_launch" in dv and launch_ms:
+        out["beyond_l2_GBps"] = dv["hbm_bytes_per_launch"] / (launch_ms * 1e-3) / 1e9
+        out["measured_hbm_frac"] = out["beyond_l2_GBps"] / HBM_PEAK_GBS
+    return out
+
+
 def cpu_baseline(scene_file, width, height, spp, step):
     """Times the oracle (test infrastructure, used here only as the reported CPU baseline) on one core."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -74,7 +95,7 @@ def cpu_baseline(scene_file, width, height, spp, step):
                       f"full nearest-hit shadow rays to every light)"}
 
 
-def time_config(m, api, torch, raw, w, h, spp, steps, label, options=None):
+def time_config(m, api, torch, raw, w, h, spp, steps, label, options=None, pmc_workload=None):
     """A few serial frames of one more configuration on this GPU (N = 1): counters in an untimed pass, then `steps` timed frames."""
     old = {}
     for k, v in (options or {}).items():
@@ -99,11 +120,15 @@ def time_config(m, api, torch, raw, w, h, spp, steps, label, options=None):
     del img
     ab = algorithmic_bytes(st)
     kms = ks["trace_kernel_ms_mean"]
-    return {"workload": label, "ms_per_frame": dt * 1e3, "trace_kernel_ms": kms, "Mrays_per_s": st["rays"] / dt / 1e6, "rays_per_frame": st["rays"],
-            "node_visits_per_ray": st["internal_visits"] / max(st["rays"], 1),
-            "leaf_tests_per_ray": (st["sphere_tests"] + st["tri_tests"]) / max(st["rays"], 1),
-            "algorithmic_GBps": ab / (kms * 1e-3) / 1e9, "frac": ab / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS, "frames_timed": steps,
-            "options": options or {}}
+    out = {"workload": label, "ms_per_frame": dt * 1e3, "trace_kernel_ms": kms, "Mrays_per_s": st["rays"] / dt / 1e6, "rays_per_frame": st["rays"],
+           "node_visits_per_ray": st["internal_visits"] / max(st["rays"], 1),
+           "leaf_tests_per_ray": (st["sphere_tests"] + st["tri_tests"]) / max(st["rays"], 1),
+           "algorithmic_GBps": ab / (kms * 1e-3) / 1e9, "frac": ab / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS, "frames_timed": steps,
+           "options": options or {}}
+    lim = committed_limiter(pmc_workload or label) if not options else None      # (counter passes exist for the default options only)
+    if lim:
+        out["limiter"] = lim
+    return out
 
 
 def main():
@@ -339,7 +364,9 @@ def main():
             r5 = m.initRawConfigFromStl(s5, local_rank)
             b5 = m.build_lbvh_karas(r5)
             lab = f"synthetic 1M spheres + 1M triangles 3840x2160 {args.config5_spp}spp (whole frame on this GPU)"
-            c5 = time_config(m, api, torch, r5, 3840, 2160, args.config5_spp, 1, lab)
+            # (its counter passes were taken on the same scene and frame size at 8 spp: one slab = one launch of the same kernel)
+            c5 = time_config(m, api, torch, r5, 3840, 2160, args.config5_spp, 1, lab,
+                             pmc_workload="synthetic 1M spheres + 1M triangles 3840x2160 8spp (BASELINE config 5 scene, one slab)")
             c5["lbvh_build_ms"] = b5
             c5["note"] = "default traversal: near-child-first only where both subtrees hold spheres only -- bit-identical to the reference's order by construction"
             extra.append(c5)
