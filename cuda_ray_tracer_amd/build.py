@@ -48,7 +48,7 @@ def build(force=False, verbose=False):
     hipcc = _hipcc()
     deps = _all_deps()
     extra = []
-    for var in ("MIRT_WAVES_PER_SIMD", "MIRT_STACK_LDS", "MIRT_WF_WAVES_PER_SIMD", "MIRT_WF_SHADE_WAVES", "MIRT_WF_QUAD_FETCH", "MIRT_TRACE_BLOCK"):      # tuning experiments only; defaults live in render.hip
+    for var in ("MIRT_WAVES_PER_SIMD", "MIRT_STACK_LDS", "MIRT_WF_WAVES_PER_SIMD", "MIRT_WF_SHADE_WAVES", "MIRT_TRACE_BLOCK"):      # tuning experiments only; defaults live in render.hip
         if os.environ.get(var):
             extra.append(f"-D{var}=" + os.environ[var])
     objs = []

@@ -39,7 +39,7 @@ const OptionDesc OPTIONS[] = {
   {"traversal", &Options::traversal, 0, 2}, {"wavefront", &Options::wavefront, 0, 1},
   {"stack_lds_depth", &Options::stack_lds_depth, -1, 64}, {"refill_k", &Options::refill_k, 0, 64}, {"batch_k", &Options::batch_k, 1, 64},
   {"leaf_k", &Options::leaf_k, 1, 64}, {"reps", &Options::reps, 1, 8}, {"drain_lanes", &Options::drain_lanes, 0, 64},
-  {"chunk_shift", &Options::chunk_shift, 0, 12}, {"trace_waves", &Options::trace_waves, 0, 1 << 20}, {"sched", &Options::sched, 0, 1}, {"qnodes", &Options::qnodes, 0, 1}, {"specialise", &Options::specialise, 0, 1}, {"slab_log2", &Options::slab_log2, 8, 30},
+  {"chunk_shift", &Options::chunk_shift, 0, 12}, {"trace_waves", &Options::trace_waves, 0, 1 << 20}, {"sched", &Options::sched, 0, 1}, {"qnodes", &Options::qnodes, 0, 1}, {"shadow_anyhit", &Options::shadow_anyhit, 0, 1}, {"skip_unlit", &Options::skip_unlit, 0, 1}, {"specialise", &Options::specialise, 0, 1}, {"slab_log2", &Options::slab_log2, 8, 30},
   {"wf_pool", &Options::wf_pool, 256, 1 << 24}, {"wf_refill_k", &Options::wf_refill_k, 1, 64},
 };
 
@@ -250,7 +250,7 @@ void mirt_scene_destroy(MirtScene* sc)
   hipFree(sc->bounds_keys); hipFree(sc->qparams);
   for (int i = 0; i < mirt::MIRT_MAX_FRAMES; ++i) {
     mirt::RenderCtx& c = sc->ctx[i];
-    hipFree(c.samples); hipFree(c.stack_spill); hipFree(c.pending); hipFree(c.counters); hipFree(c.prof); hipFree(c.args_dev);
+    hipFree(c.samples); hipFree(c.stack_spill); hipFree(c.pending); hipFree(c.counters); hipFree(c.args_dev);
     hipFree(c.chunk_cost); for (uint32_t* o : c.order_out) hipFree(o);
     if (c.ev0) hipEventDestroy(c.ev0);
     if (c.ev1) hipEventDestroy(c.ev1);

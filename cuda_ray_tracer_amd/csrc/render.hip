@@ -51,16 +51,10 @@ constexpr int MAX_CHUNK_SHIFT = 8, MIN_CHUNK_SHIFT = 6;   // a wave takes 64..25
 constexpr int STACK_LDS = MIRT_STACK_LDS;
 // QN: the scene's nodes are 32-byte quantised records (sphere-only scenes, scene_dev.h); SPECX: SPEC_NOBULB / SPEC_NOPEND of
 // shade_common.h (instantiated: both or none with QN; both, SPEC_NOBULB or none without)
-template <bool COUNT, bool PROF, int TABLES, bool QN, int SPECX = 0>
+template <bool COUNT, int TABLES, bool QN, int SPECX = 0>
 __global__ void __launch_bounds__(TRACE_BLOCK, MIRT_WAVES_PER_SIMD) trace_kernel(const RenderArgs* __restrict__ ap, const HotArgs h)
 {
   constexpr int SPEC = (QN ? SPEC_NOTRI : 0) | SPECX;
-  // PROF: diagnostic build only -- cycle stamps per phase, written to h.prof (never used for timing claims)
-  unsigned long long pf_S = 0, pf_T = 0, pf_iters = 0, pf_active = 0, pf_Sent = 0, pf_Slanes = 0, pf_Bent = 0, pf_Blanes = 0, pf_leaf = 0, pf_node = 0;
-  const unsigned long long pf_t0 = PROF ? clock64() : 0;
-  const unsigned long long pf_w0 = PROF ? wall_clock64() : 0;   // 100 MHz
-  unsigned long long pf_adv = 0, pf_adv_it = 0, pf_init = 0, pf_Bcyc = 0;
-  unsigned long long pf_tx = 0, pf_xit = 0, pf_xS = 0, pf_dit = 0, pf_xact = 0;
   __shared__ __attribute__((aligned(16))) unsigned char lds_raw[STACK_LDS * TRACE_BLOCK * 4];     // traversal stacks: STACK_LDS x TRACE_BLOCK words
   // The random-number state (8 words per lane) is only touched in the shade phase: it lives here during traversal so
   // that it does not occupy registers across the hot loop (the kernel runs at the 128-VGPR edge of 4 waves per SIMD).
@@ -105,9 +99,6 @@ __global__ void __launch_bounds__(TRACE_BLOCK, MIRT_WAVES_PER_SIMD) trace_kernel
   lds_park[1][tid] = make_uint4(0, 0, 0, __float_as_uint(1.458f));
   for (;;) {
     // ================= shade / refill phase: lanes that are not traversing =================
-    unsigned long long pf_a = 0;
-    if (PROF && exhausted) pf_xS++;
-    if (PROF) { pf_a = clock64(); pf_Sent++; pf_Slanes += __popcll(__ballot(!S.trav && S.g >= 0)); }
     // The shade phase reads the frame's RenderArgs through a pointer the optimiser cannot see through, so that those
     // values are (scalar-)loaded here and do not live in registers across the traversal loop.
     const RenderArgs* aq = ap;
@@ -125,9 +116,7 @@ __global__ void __launch_bounds__(TRACE_BLOCK, MIRT_WAVES_PER_SIMD) trace_kernel
     while (!S.trav && S.g >= 0 && !(exhausted && S.batch_pending)) {
       if (S.batch_pending) batch_next<COUNT, QN, RenderArgs, SPEC>(a, S, cn);
       else advance<COUNT, QN, SPEC>(a, S, cn, gid, gthreads);
-      if (PROF) pf_adv_it++;
     }
-    if (PROF) pf_adv += clock64() - pf_a;
     if (!exhausted) {
       const unsigned long long need = __ballot(!S.trav && S.g < 0);
       if (need) {
@@ -147,7 +136,7 @@ __global__ void __launch_bounds__(TRACE_BLOCK, MIRT_WAVES_PER_SIMD) trace_kernel
               if (k < nchunks && a.chunk_order) k = a.chunk_order[k];
             }
             k = __shfl(k, 0);
-            if (k >= nchunks) { exhausted = true; if (PROF && pf_tx == 0) pf_tx = wall_clock64(); break; }
+            if (k >= nchunks) { exhausted = true; break; }
             c_next = k << a.chunk_shift;
             c_end = (c_next + chunk < nsamples) ? c_next + chunk : nsamples;
           }
@@ -157,9 +146,7 @@ __global__ void __launch_bounds__(TRACE_BLOCK, MIRT_WAVES_PER_SIMD) trace_kernel
           c_next += (unsigned long long)take;
           given += take;
         }
-        const unsigned long long pf_i0 = PROF ? clock64() : 0;
         if (my >= 0) init_sample<COUNT, TABLES, QN>(a, S, cn, my);
-        if (PROF) pf_init += clock64() - pf_i0;
       }
     }
     lds_rng[0][tid] = make_uint4(S.rng.v0, S.rng.v1, S.rng.v2, S.rng.v3);
@@ -173,8 +160,6 @@ __global__ void __launch_bounds__(TRACE_BLOCK, MIRT_WAVES_PER_SIMD) trace_kernel
 
     // ================= traversal phase: traverse_lbvh, bvh_traversal.cu:92-183 =================
     const float tmin = 0.0001f;
-    unsigned long long pf_b = 0;
-    if (PROF) { pf_b = clock64(); pf_S += pf_b - pf_a; }
     for (;;) {
       const unsigned long long tm = __ballot(S.trav);
       const unsigned long long bm = __ballot(!S.trav && S.batch_pending);
@@ -189,13 +174,8 @@ __global__ void __launch_bounds__(TRACE_BLOCK, MIRT_WAVES_PER_SIMD) trace_kernel
       if (nwait >= h.refill_k || (drain && nwait > 0)) break;
       // lanes whose batch ray finished move on to the next ray of their batch (cheap; done in groups)
       if (bm != 0 && (__popcll(bm) >= h.batch_k || tm == 0 || drain)) {
-        if (PROF) { pf_Bent++; pf_Blanes += __popcll(bm); }
-        const unsigned long long pf_b0 = PROF ? clock64() : 0;
         if (!S.trav && S.batch_pending) batch_next<COUNT, QN, HotArgs, SPEC>(h, S, cn);
-        if (PROF) pf_init += 0, pf_Bcyc += clock64() - pf_b0;
       }
-      if (PROF && exhausted) { pf_xit++; pf_xact += __popcll(__ballot(S.trav)); if (drain) pf_dit++; }
-      if (PROF) { pf_iters++; pf_active += __popcll(__ballot(S.trav)); pf_leaf += __popcll(__ballot(S.trav && (S.cur & REF_LEAF))); }
       // A wave executes the node path and the primitive path one after the other whenever its lanes are split between
       // them, and with ~45 live lanes nearly every iteration has a lane or two at a primitive.  So lanes that reach a
       // primitive wait until leaf_k of them have one pending (or nothing else is left to do): the primitive code then
@@ -293,21 +273,7 @@ __global__ void __launch_bounds__(TRACE_BLOCK, MIRT_WAVES_PER_SIMD) trace_kernel
       }
       }
     }
-    if (PROF) pf_T += clock64() - pf_b;
   }
-  (void)lane;
-  if (PROF && h.prof && (tid & 63) == 0) {
-    const unsigned long long tot = clock64() - pf_t0;
-    atomicAdd(&h.prof[0], tot); atomicAdd(&h.prof[1], pf_S); atomicAdd(&h.prof[2], pf_T); atomicAdd(&h.prof[3], pf_iters);
-    atomicAdd(&h.prof[4], pf_active); atomicAdd(&h.prof[5], pf_Sent); atomicAdd(&h.prof[6], pf_Slanes); atomicAdd(&h.prof[7], pf_Bent);
-    atomicAdd(&h.prof[8], pf_Blanes); atomicAdd(&h.prof[9], pf_leaf); atomicAdd(&h.prof[10], 1ull);
-    atomicAdd(&h.prof[16 + 3 * (size_t)gridDim.x * (TRACE_BLOCK / 64)], pf_adv); atomicAdd(&h.prof[17 + 3 * (size_t)gridDim.x * (TRACE_BLOCK / 64)], pf_adv_it); atomicAdd(&h.prof[18 + 3 * (size_t)gridDim.x * (TRACE_BLOCK / 64)], pf_init); atomicAdd(&h.prof[19 + 3 * (size_t)gridDim.x * (TRACE_BLOCK / 64)], pf_Bcyc);
-    atomicAdd(&h.prof[11], pf_xit); atomicAdd(&h.prof[12], pf_xS); atomicAdd(&h.prof[14], pf_dit); atomicAdd(&h.prof[15], pf_xact);
-    // per wave: start, queue-empty and exit times (100 MHz wall clock)
-    unsigned long long* w = h.prof + 16 + 3 * (size_t)blockIdx.x * (TRACE_BLOCK / 64) + 3 * (tid >> 6);
-    w[0] = pf_w0; w[1] = pf_tx; w[2] = wall_clock64();
-  }
-  (void)pf_node;
 
   unsigned long long* const counters = COUNT ? ap->counters : nullptr;
   if (COUNT && counters) {
@@ -569,45 +535,10 @@ static int grid_blocks(int device)
   hipDeviceProp_t prop;
   if (hipGetDeviceProperties(&prop, device) != hipSuccess) return 1024;
   int per_cu = 0;
-  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, trace_kernel<false, false, 8, false>, TRACE_BLOCK, 0) != hipSuccess || per_cu < 1) per_cu = 4 * 256 / TRACE_BLOCK;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, trace_kernel<false, 8, false>, TRACE_BLOCK, 0) != hipSuccess || per_cu < 1) per_cu = 4 * 256 / TRACE_BLOCK;
   return prop.multiProcessorCount * per_cu;
 }
 
-#if MIRT_DIAG_PROF
-// diagnostic build only (tools/ab.py NAME -DMIRT_DIAG_PROF=1, MIRT_PROF=1): per-phase cycle stamps of the trace kernel
-static int report_prof(RenderCtx& cx, int blocks, hipStream_t stream)
-{
-  MIRT_HIP(hipStreamSynchronize(stream));
-  unsigned long long hh[16];
-  MIRT_HIP(hipMemcpy(hh, cx.prof, sizeof(hh), hipMemcpyDeviceToHost));
-  fprintf(stderr, "[mirt prof] waves=%llu cyc/wave=%.3g S=%.1f%% T=%.1f%% | T-iters/wave=%.0f active/iter=%.1f leaf-lanes/iter=%.1f | S-entries/wave=%.0f lanes/entry=%.1f | B-entries/wave=%.0f lanes/entry=%.1f\n",
-          hh[10], (double)hh[0] / hh[10], 100.0 * hh[1] / hh[0], 100.0 * hh[2] / hh[0], (double)hh[3] / hh[10], (double)hh[4] / (hh[3] ? hh[3] : 1), (double)hh[9] / (hh[3] ? hh[3] : 1),
-          (double)hh[5] / hh[10], (double)hh[6] / (hh[5] ? hh[5] : 1), (double)hh[7] / hh[10], (double)hh[8] / (hh[7] ? hh[7] : 1));
-  {
-    unsigned long long ad[4];
-    MIRT_HIP(hipMemcpy(ad, cx.prof + 16 + 3 * (size_t)blocks * (TRACE_BLOCK / 64), sizeof(ad), hipMemcpyDeviceToHost));
-    fprintf(stderr, "[mirt prof] shade phase: %.1f%% of it in the advance/batch loop (%.2f passes per entry), %.1f%% in init_sample, the rest in the chunk hand-out and the RNG / state moves\n",
-            100.0 * ad[0] / (hh[1] ? hh[1] : 1), (double)ad[1] / (hh[5] ? hh[5] : 1), 100.0 * ad[2] / (hh[1] ? hh[1] : 1));
-    fprintf(stderr, "[mirt prof] traversal phase: %.1f%% of it in the batch transitions of the loop header (batch_next + start_ray)\n", 100.0 * ad[3] / (hh[2] ? hh[2] : 1));
-  }
-  fprintf(stderr, "[mirt prof] after the queue is empty, per wave: %.0f iterations (%.1f lanes traversing, %.0f in drain mode), %.1f shade-phase entries\n",
-          (double)hh[11] / hh[10], (double)hh[15] / (hh[11] ? hh[11] : 1), (double)hh[14] / hh[10], (double)hh[12] / hh[10]);
-  {
-    const size_t nwaves = (size_t)blocks * (TRACE_BLOCK / 64);
-    std::vector<unsigned long long> w(3 * nwaves);
-    MIRT_HIP(hipMemcpy(w.data(), cx.prof + 16, w.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
-    unsigned long long t0 = ~0ull;
-    for (size_t i = 0; i < nwaves; ++i) if (w[3 * i] && w[3 * i] < t0) t0 = w[3 * i];
-    std::vector<double> st, ex, en;
-    for (size_t i = 0; i < nwaves; ++i) { st.push_back((w[3 * i] - t0) * 1e-5); ex.push_back(((w[3 * i + 1] ? w[3 * i + 1] : w[3 * i + 2]) - t0) * 1e-5); en.push_back((w[3 * i + 2] - t0) * 1e-5); }
-    std::sort(st.begin(), st.end()); std::sort(ex.begin(), ex.end()); std::sort(en.begin(), en.end());
-    auto q = [&](const std::vector<double>& v, double f) { return v[(size_t)(f * (v.size() - 1))]; };
-    fprintf(stderr, "[mirt prof] per-wave times, ms (min/10%%/50%%/90%%/max): start %.2f/%.2f/%.2f/%.2f/%.2f | queue empty %.2f/%.2f/%.2f/%.2f/%.2f | exit %.2f/%.2f/%.2f/%.2f/%.2f\n",
-            q(st, 0), q(st, .1), q(st, .5), q(st, .9), q(st, 1), q(ex, 0), q(ex, .1), q(ex, .5), q(ex, .9), q(ex, 1), q(en, 0), q(en, .1), q(en, .5), q(en, .9), q(en, 1));
-  }
-  return MIRT_OK;
-}
-#endif
 
 // One call of mirt_render / mirt_render_accumulate.  The part's pixels are rendered in slabs of at most 2^slab_log2 samples,
 // so the per-sample workspace is bounded (1 GiB by default) whatever the frame: BASELINE config 5 (3840x2160 x 256 spp,
@@ -712,7 +643,8 @@ static int render_impl(MirtScene* sc, const MirtRenderParams* p, void* d_rgba8, 
   a.qparams = qn ? sc->qparams : nullptr;
   a.prim_base16 = sc->prim_base / 16u;
   a.swap_mask = opt.traversal == 1 ? NODE_SWAP_PURE : (opt.traversal == 2 ? NODE_SWAP_ANY : 0u);
-  a.skip_unlit = (sc->colors_finite && sc->d.num_suns + sc->d.num_bulbs <= 32) ? 1 : 0;
+  a.skip_unlit = (opt.skip_unlit != 0 && sc->colors_finite && sc->d.num_suns + sc->d.num_bulbs <= 32) ? 1 : 0;
+  a.shadow_anyhit = opt.shadow_anyhit != 0 ? 1 : 0;
   a.planes = sc->planes; a.num_planes = sc->d.num_planes;
   a.suns = sc->suns; a.num_suns = sc->d.num_suns;
   a.bulbs = sc->bulbs; a.num_bulbs = sc->d.num_bulbs;
@@ -771,28 +703,15 @@ static int render_impl(MirtScene* sc, const MirtRenderParams* p, void* d_rgba8, 
   if (sched) MIRT_HIP(hipMemsetAsync(cx.chunk_cost, 0, 4 * nchunks, stream));
   if (count) MIRT_HIP(hipMemsetAsync(cx.counters, 0, 8 * sizeof(unsigned long long), stream));
   a.work_counter = cx.counters + 8;
-#if MIRT_DIAG_PROF
-  const bool prof = getenv("MIRT_PROF") != nullptr;
-#else
-  const bool prof = false;
-#endif
   cx.wf_trace_ms = -1.0f;
   float wf_ms_total = 0.0f;
   HotArgs h;
   h.nodes = a.nodes; h.root_ref = a.root_ref; h.swap_mask = a.swap_mask; h.qparams = a.qparams;
-  h.planes = a.planes; h.num_planes = a.num_planes; h.suns = a.suns; h.num_suns = a.num_suns; h.bulbs = a.bulbs; h.num_bulbs = a.num_bulbs;
+  h.planes = a.planes; h.num_planes = a.num_planes; h.suns = a.suns; h.num_suns = a.num_suns; h.bulbs = a.bulbs; h.num_bulbs = a.num_bulbs; h.shadow_anyhit = a.shadow_anyhit;
   h.stack_spill = a.stack_spill; h.lds_depth = a.lds_depth; h.refill_k = a.refill_k; h.batch_k = a.batch_k; h.drain_lanes = a.drain_lanes;
   h.leaf_k = opt.leaf_k;
   h.reps = opt.reps;
-  h.prof = nullptr;
   if (!wavefront && !cx.args_dev) MIRT_HIP(hipMalloc(&cx.args_dev, sizeof(RenderArgs) * MAX_SLAB_ARGS));
-  if (prof) {
-    const size_t nwaves = (size_t)blocks * (TRACE_BLOCK / 64);
-    if (cx.prof) { hipFree(cx.prof); cx.prof = nullptr; }
-    MIRT_HIP(hipMalloc(&cx.prof, (20 + 3 * nwaves) * sizeof(unsigned long long)));
-    MIRT_HIP(hipMemsetAsync(cx.prof, 0, (20 + 3 * nwaves) * sizeof(unsigned long long), stream));
-    a.prof = cx.prof; h.prof = cx.prof;
-  }
   int P = 1, lg = 0;
   while (P < sample_count) { P <<= 1; ++lg; }
 
@@ -814,18 +733,10 @@ static int render_impl(MirtScene* sc, const MirtRenderParams* p, void* d_rgba8, 
       // does not wait for the kernel of slab k (the stream orders a copy after the kernel that used the same slot)
       RenderArgs* adev = cx.args_dev + (slab % MAX_SLAB_ARGS);
       MIRT_HIP(hipMemcpyAsync(adev, &a, sizeof(RenderArgs), hipMemcpyHostToDevice, stream));
-#if MIRT_DIAG_PROF
-      if (prof) {
-        if (qn) hipLaunchKernelGGL((trace_kernel<false, true, 0, true>), dim3(blocks), dim3(TRACE_BLOCK), 0, stream, adev, h);
-        else hipLaunchKernelGGL((trace_kernel<false, true, 0, false>), dim3(blocks), dim3(TRACE_BLOCK), 0, stream, adev, h);
-        int rc = report_prof(cx, blocks, stream);
-        if (rc != MIRT_OK) return rc;
-      } else
-#endif
       // one instantiation per form of the random-number tables (device_common.h, xw_init) and per node format
       {
         const bool t8 = a.needs_rng && a.rng.mode == 0 && a.rng.chunk_bits == 8;
-#define MIRT_LAUNCH(C, T, Q, P) hipLaunchKernelGGL((trace_kernel<C, false, T, Q, P>), dim3(blocks), dim3(TRACE_BLOCK), 0, stream, adev, h)
+#define MIRT_LAUNCH(C, T, Q, P) hipLaunchKernelGGL((trace_kernel<C, T, Q, P>), dim3(blocks), dim3(TRACE_BLOCK), 0, stream, adev, h)
 #define MIRT_LAUNCH_T(C, Q, P) do { if (t8) MIRT_LAUNCH(C, 8, Q, P); else MIRT_LAUNCH(C, 4, Q, P); } while (0)
 #define MIRT_LAUNCH_Q(C) do { if (qn && nobulb && nopend) MIRT_LAUNCH_T(C, true, SPEC_NOBULB | SPEC_NOPEND); else if (qn) MIRT_LAUNCH_T(C, true, 0); \
                               else if (nobulb && nopend) MIRT_LAUNCH_T(C, false, SPEC_NOBULB | SPEC_NOPEND); \

@@ -63,6 +63,7 @@ struct RenderArgs {
   uint32_t prim_base16;           // offset of the primitive region in the heap, in 16-byte units
   uint32_t swap_mask;             // NODE_SWAP_* bits that allow near-child-first descent (0: the reference's left-first order)
   int skip_unlit;                 // 1: shadow rays towards lights the shading normal faces away from are not traced (all colours finite)
+  int shadow_anyhit;              // 1: a shadow ray ends at its first occluder; 0: nearest-hit query like every other ray (draw.cu:347-352)
   const float* qparams;           // quantised nodes in use: grid origin xyz, grid step xyz (else null)
   int num_spheres;
   int num_prims;
@@ -83,7 +84,6 @@ struct RenderArgs {
   int batch_k;                    // start the next rays of ray batches when this many lanes wait for one
   unsigned long long* counters;   // MirtStats head (8 x u64) or null
   unsigned long long* overflow;   // never null: capacity overflows (traversal stack beyond 64, pending list), must stay 0
-  unsigned long long* prof;       // diagnostic build only (MIRT_PROF)
   unsigned long long* work_counter; // next unclaimed chunk of the frame (single-kernel path)
   const uint32_t* chunk_order;      // chunk k of the hand-out order is chunk chunk_order[k] of the frame (null: identity)
   int chunk_shift;                  // log2 of the number of consecutive samples a wave takes from the frame per atomic
@@ -101,11 +101,11 @@ struct HotArgs {
   const PlaneDev* planes; int num_planes;
   const LightDev* suns; int num_suns;
   const LightDev* bulbs; int num_bulbs;
+  int shadow_anyhit;
   uint32_t* stack_spill;
   int lds_depth, refill_k, batch_k, drain_lanes;
   int reps;                       // traversal steps per pass through the loop header
   int leaf_k;                     // primitive tests are held back until this many lanes of the wave have one pending
-  unsigned long long* prof;
 };
 
 struct ResolveArgs {
@@ -140,6 +140,8 @@ struct Options {
   int batch_k = 8, leaf_k = 8, reps = 4, drain_lanes = 16;
   int chunk_shift = 0;         // 0: by frame size
   int trace_waves = 0;         // 0: fill the device
+  int shadow_anyhit = 1;       // 0: shadow rays are nearest-hit queries, as in diffuseLight (draw.cu:347-352, 365-370): the reference's walk, more node visits
+  int skip_unlit = 1;          // 0: shadow rays towards lights the shading normal faces away from are traced as well (draw.cu:342-374 traces them all)
   int qnodes = 1;              // sphere-only scenes: 32-byte quantised node records in the single-kernel path (traversal >= 1)
   int specialise = 1;          // kernels compiled without what the scene does not have: point lights; transparency and gi (SPEC_*, shade_common.h)
   int sched = 1;               // longest-first chunk order measured on earlier frames
@@ -154,7 +156,6 @@ struct RenderCtx {
   uint32_t* stack_spill = nullptr; size_t spill_cap = 0;
   float* pending = nullptr; size_t pending_cap = 0;
   unsigned long long* counters = nullptr;  // device: [0..7] MirtStats counters, [8] work counter
-  unsigned long long* prof = nullptr;      // diagnostic stamps (MIRT_PROF)
   hipStream_t stream = nullptr;            // the stream this context's latest frame was issued on
   RenderArgs* args_dev = nullptr;          // this frame's RenderArgs in device memory
   hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr, ev3 = nullptr;   // render start / trace start / trace end / render end

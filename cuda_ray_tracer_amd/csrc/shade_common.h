@@ -302,8 +302,8 @@ struct Lane {
 template <bool COUNT, bool HAVE_INV = false, bool QN = false, typename Args = RenderArgs>
 MIRT_DEV void start_ray(const Args& a, Lane& S, Counters& cn)
 {
-  const bool shadow = S.shadow;
-  if (COUNT) { cn.rays++; if (shadow) cn.shadow_rays++; }
+  const bool shadow = S.shadow;      // (an any-hit shadow ray: batch_next)
+  if (COUNT) cn.rays++;
   if (!HAVE_INV) S.inv = mk3(1.0f / S.d.x, 1.0f / S.d.y, 1.0f / S.d.z);
   if (QN) {
     // the ray in the grid of the quantised node records (uniform values: scalar loads)
@@ -394,8 +394,11 @@ MIRT_DEV void batch_next(const Args& a, Lane& S, Counters& cn)
     // shadow ray, draw.cu:346 / 362-363
     S.o = S.bo;
     S.limit = INFINITY;
-    S.shadow = true;
+    // shadow_anyhit = 0: the ray is traced to its nearest hit like any other, exactly as hitNearest does for diffuseLight
+    // (draw.cu:347-352, 365-370); the occlusion test above reads the same boolean off the result either way
+    S.shadow = a.shadow_anyhit != 0;
     S.bounce = 1;
+    if (COUNT) cn.shadow_rays++;
     if (NOBULB || S.li < a.num_suns) {
       // direction and its reciprocal are per-light constants (host-computed, same arithmetic)
       const LightDev& lt = a.suns[S.li];
@@ -421,14 +424,23 @@ MIRT_DEV void batch_next(const Args& a, Lane& S, Counters& cn)
   if (go) start_ray<COUNT, true, QN>(a, S, cn);
 }
 
+// The pending-children LIFO of a lane (refraction / gi children waiting for their turn): one 64-byte entry per slot, a lane's
+// slots next to each other -- a push writes one cache line and the pop that follows reads it back from the L2 (with the words
+// of an entry strided by the grid size, as in rounds 1-2, each of an entry's eleven words dirtied a line of its own).
+MIRT_DEV float4* pending_entry(const RenderArgs& a, const long long gid, const int slot)
+{
+  return reinterpret_cast<float4*>(a.pending) + ((size_t)gid * (size_t)a.pending_slots + (size_t)slot) * (PENDING_WORDS / 4);
+}
+
 // Consume the finished trace of lane S and run its shading state machine until it either has the next ray(s) or the
 // sample is complete.  Returns M_DONE (sample finished: S.L / S.alpha hold the RGBA), M_BATCH (a new shading node was
 // entered: S.bo, S.rdir, S.has_reflect describe its ray batch, S.li = -1) or M_TRACE (a single ray is in S.o/S.d/S.bounce).
-// `gid`/`gthreads` address this lane's column of the pending-children LIFO (a.pending).
+// `gid` names this lane's pending-children LIFO (pending_entry).
 template <bool COUNT, int SPEC = 0>
 MIRT_DEV int advance_core(const RenderArgs& a, Lane& S, Counters& cn, const long long gid, const long long gthreads)
 {
   constexpr bool NOTRI = (SPEC & SPEC_NOTRI) != 0, NOBULB = (SPEC & SPEC_NOBULB) != 0, NOPEND = (SPEC & SPEC_NOPEND) != 0;
+  (void)gthreads;
   const int nlights = NOBULB ? a.num_suns : a.num_suns + a.num_bulbs;
   int micro = M_TRACE;
   const bool bvh_hit = S.refbest != REF_NONE;
@@ -532,24 +544,19 @@ MIRT_DEV int advance_core(const RenderArgs& a, Lane& S, Counters& cn, const long
       if (XtransNZ && Xbounce > 0 && S.pc + ((has_gi && a.gi != 0 && S.gi_n != 0) ? 1 : 0) >= a.pending_slots) atomicAdd(a.overflow, 1ull);
       if (has_gi && a.gi != 0 && S.gi_n != 0 && S.pc < a.pending_slots) {
         const f3 w = (S.wt * K) * nm.color;
-        float* e = a.pending + ((size_t)S.pc * PENDING_WORDS) * gthreads + gid;
-        e[0 * gthreads] = __uint_as_float(PEND_G);
-        e[1 * gthreads] = S.Hp.x; e[2 * gthreads] = S.Hp.y; e[3 * gthreads] = S.Hp.z;
-        e[4 * gthreads] = S.Hn.x; e[5 * gthreads] = S.Hn.y; e[6 * gthreads] = S.Hn.z;
-        e[7 * gthreads] = __int_as_float(S.gi_n);
-        e[8 * gthreads] = w.x; e[9 * gthreads] = w.y; e[10 * gthreads] = w.z;
+        float4* e = pending_entry(a, gid, S.pc);
+        e[0] = make_float4(__uint_as_float(PEND_G), S.Hp.x, S.Hp.y, S.Hp.z);
+        e[1] = make_float4(S.Hn.x, S.Hn.y, S.Hn.z, __int_as_float(S.gi_n));
+        e[2] = make_float4(w.x, w.y, w.z, 0.0f);
         ++S.pc;
       }
       if (XtransNZ && Xbounce > 0 && S.pc < a.pending_slots) {
         const f3 w = S.wt * ((one - Sh) * T);
-        float* e = a.pending + ((size_t)S.pc * PENDING_WORDS) * gthreads + gid;
-        e[0 * gthreads] = __uint_as_float(PEND_F);
-        e[1 * gthreads] = Xp.x; e[2 * gthreads] = Xp.y; e[3 * gthreads] = Xp.z;
-        e[4 * gthreads] = Xn.x; e[5 * gthreads] = Xn.y; e[6 * gthreads] = Xn.z;
-        e[7 * gthreads] = __int_as_float(Xbounce);
-        e[8 * gthreads] = w.x; e[9 * gthreads] = w.y; e[10 * gthreads] = w.z;
-        e[11 * gthreads] = Xdir.x; e[12 * gthreads] = Xdir.y; e[13 * gthreads] = Xdir.z;
-        e[14 * gthreads] = Xior;
+        float4* e = pending_entry(a, gid, S.pc);
+        e[0] = make_float4(__uint_as_float(PEND_F), Xp.x, Xp.y, Xp.z);
+        e[1] = make_float4(Xn.x, Xn.y, Xn.z, __int_as_float(Xbounce));
+        e[2] = make_float4(w.x, w.y, w.z, Xdir.x);
+        e[3] = make_float4(Xdir.y, Xdir.z, Xior, 0.0f);
         ++S.pc;
       }
       S.wD = S.wt * K;
@@ -583,12 +590,13 @@ MIRT_DEV int advance_core(const RenderArgs& a, Lane& S, Counters& cn, const long
       if (NOPEND || S.pc == 0) micro = M_DONE;
       else {
         --S.pc;
-        const float* e = a.pending + ((size_t)S.pc * PENDING_WORDS) * gthreads + gid;
-        const uint32_t tag = __float_as_uint(e[0 * gthreads]);
-        const f3 p = mk3(e[1 * gthreads], e[2 * gthreads], e[3 * gthreads]);
-        const f3 n = mk3(e[4 * gthreads], e[5 * gthreads], e[6 * gthreads]);
-        const int ib = __float_as_int(e[7 * gthreads]);
-        S.wt = mk3(e[8 * gthreads], e[9 * gthreads], e[10 * gthreads]);
+        const float4* e = pending_entry(a, gid, S.pc);
+        const float4 e0 = e[0], e1 = e[1], e2 = e[2];
+        const uint32_t tag = __float_as_uint(e0.x);
+        const f3 p = mk3(e0.y, e0.z, e0.w);
+        const f3 n = mk3(e1.x, e1.y, e1.z);
+        const int ib = __float_as_int(e1.w);
+        S.wt = mk3(e2.x, e2.y, e2.z);
         if (tag == PEND_G) {
           // globalIllumination, draw.cu:540-549
           const f3 gi_dir = normalize(n + sphere_point(S.rng));
@@ -598,8 +606,9 @@ MIRT_DEV int advance_core(const RenderArgs& a, Lane& S, Counters& cn, const long
           micro = (S.bounce == 0) ? M_POP : M_TRACE;
         } else {
           // refractionLight, draw.cu:456-480
-          const f3 dir = mk3(e[11 * gthreads], e[12 * gthreads], e[13 * gthreads]);
-          const float ior = 1.0f / e[14 * gthreads];
+          const float4 e3 = e[3];
+          const f3 dir = mk3(e2.w, e3.x, e3.y);
+          const float ior = 1.0f / e3.z;
           const f3 normal = normalize(n);
           const float dn = dot(normal, dir);
           const float k = 1.0f - (ior * ior) * (1.0f - (dn * dn));
@@ -696,55 +705,6 @@ MIRT_DEV void init_sample(const RenderArgs& a, Lane& S, Counters& cn, const long
   } else {
     start_ray<COUNT, false, QN>(a, S, cn);
   }
-}
-
-// ---- quad-cooperative record fetch ----------------------------------------------------------------------------------
-// Every ray needs the 64-byte record its `cur` names.  Loading it lane by lane costs four divergent 16-byte requests per
-// ray in the texture addresser / L1 tag pipeline, which is what bounds the lean traversal kernel.  Here the four lanes of
-// a quad serve each other: in round j each lane loads quarter (lane & 3) of quad-lane j's record, so one wave instruction
-// touches each record once as a contiguous 64 bytes; a 4x4 transpose over the quad (two DPP butterfly stages) then hands
-// every lane its own record.  Must be called with all 64 lanes active (DPP reads neighbours).
-#define MIRT_DPP_XOR1 0xB1   /* quad_perm [1,0,3,2] */
-#define MIRT_DPP_XOR2 0x4E   /* quad_perm [2,3,0,1] */
-template <int CTRL>
-MIRT_DEV float4 dpp4(const float4& v)
-{
-  float4 r;
-  r.x = __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v.x), CTRL, 0xf, 0xf, true));
-  r.y = __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v.y), CTRL, 0xf, 0xf, true));
-  r.z = __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v.z), CTRL, 0xf, 0xf, true));
-  r.w = __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v.w), CTRL, 0xf, 0xf, true));
-  return r;
-}
-MIRT_DEV float4 sel4(bool c, const float4& a, const float4& b) { return make_float4(c ? a.x : b.x, c ? a.y : b.y, c ? a.z : b.z, c ? a.w : b.w); }
-template <int CTRL>
-MIRT_DEV void quad_swap(bool hi, float4& a, float4& b)
-{
-  const float4 recv = dpp4<CTRL>(sel4(hi, a, b));
-  a = sel4(hi, recv, a);
-  b = sel4(hi, b, recv);
-}
-// off: byte offset of this lane's record in the heap, or 0xffffffff when the lane has nothing to fetch
-MIRT_DEV void quad_fetch(const unsigned char* __restrict__ heap, uint32_t off, int lane, float4& q0, float4& q1, float4& q2, float4& q3)
-{
-  const uint32_t sub = (uint32_t)(lane & 3) * 16u;
-  const float4 z = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-  float4 r0 = z, r1 = z, r2 = z, r3 = z;
-  const uint32_t o0 = (uint32_t)__builtin_amdgcn_mov_dpp((int)off, 0x00, 0xf, 0xf, true);   // quad_perm [0,0,0,0]
-  const uint32_t o1 = (uint32_t)__builtin_amdgcn_mov_dpp((int)off, 0x55, 0xf, 0xf, true);   // [1,1,1,1]
-  const uint32_t o2 = (uint32_t)__builtin_amdgcn_mov_dpp((int)off, 0xAA, 0xf, 0xf, true);   // [2,2,2,2]
-  const uint32_t o3 = (uint32_t)__builtin_amdgcn_mov_dpp((int)off, 0xFF, 0xf, 0xf, true);   // [3,3,3,3]
-  if (o0 != 0xffffffffu) r0 = *reinterpret_cast<const float4*>(heap + o0 + sub);
-  if (o1 != 0xffffffffu) r1 = *reinterpret_cast<const float4*>(heap + o1 + sub);
-  if (o2 != 0xffffffffu) r2 = *reinterpret_cast<const float4*>(heap + o2 + sub);
-  if (o3 != 0xffffffffu) r3 = *reinterpret_cast<const float4*>(heap + o3 + sub);
-  // lane m holds quarter m of rays 0..3 in r0..r3; transpose so that lane i holds quarters 0..3 of ray i
-  const bool b0 = lane & 1, b1 = lane & 2;
-  quad_swap<MIRT_DPP_XOR1>(b0, r0, r1);
-  quad_swap<MIRT_DPP_XOR1>(b0, r2, r3);
-  quad_swap<MIRT_DPP_XOR2>(b1, r0, r2);
-  quad_swap<MIRT_DPP_XOR2>(b1, r1, r3);
-  q0 = r0; q1 = r1; q2 = r2; q3 = r3;
 }
 
 } // namespace

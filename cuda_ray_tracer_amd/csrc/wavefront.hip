@@ -26,9 +26,6 @@ constexpr int WBLOCK = 256;
 constexpr int SBLOCK = 512;           // shade kernel block: one queue-append atomic per 512 slots
 constexpr int WF_STACK_LDS = 16;
 constexpr int WF_CHUNK = 256;          // rays a wave takes from the queue per atomic
-#ifndef MIRT_WF_QUAD_FETCH
-#define MIRT_WF_QUAD_FETCH 0   // measured: L1 lookups -65% but +44% VALU (4x4 DPP transpose) -> trace 45.2 ms vs 41.4 ms without
-#endif
 #ifndef MIRT_WF_SHADE_WAVES
 #define MIRT_WF_SHADE_WAVES 2
 #endif
@@ -286,6 +283,7 @@ __global__ void __launch_bounds__(WBLOCK, MIRT_WF_WAVES_PER_SIMD) wf_trace_kerne
   uint32_t meta = 0, cur = REF_NONE, tos = REF_NONE, refbest = REF_NONE;
   int sp = 0, plane_id = -1;
   bool trav = false, have = false, shadow = false;
+  const bool anyhit = a.shadow_anyhit != 0;      // (0: shadow rays are nearest-hit queries, draw.cu:347-352)
   // wave-local part of the queue
   unsigned int c_next = 0, c_end = 0;
   bool queue_empty = false;
@@ -348,7 +346,7 @@ __global__ void __launch_bounds__(WBLOCK, MIRT_WF_WAVES_PER_SIMD) wf_trace_kerne
           }
           if (tplane >= (float)(INT_MAX - 10)) { tplane = INFINITY; plane_id = -1; }
           tbest = INFINITY; refbest = REF_NONE; cur = a.root_ref; sp = 0;
-          trav = (a.root_ref != REF_NONE) && !(shadow && plane_id >= 0 && tplane < limit);
+          trav = (a.root_ref != REF_NONE) && !(shadow && anyhit && plane_id >= 0 && tplane < limit);
         }
       }
     }
@@ -358,27 +356,15 @@ __global__ void __launch_bounds__(WBLOCK, MIRT_WF_WAVES_PER_SIMD) wf_trace_kerne
     }
 
     // ================= one traversal step: traverse_lbvh, bvh_traversal.cu:92-183 =================
-#if MIRT_WF_QUAD_FETCH
-    float4 q0, q1, q2, q3;
-    {
-      uint32_t off = 0xffffffffu;
-      if (trav) {
-        off = cur << 4;
-      }
-      quad_fetch(reinterpret_cast<const unsigned char*>(a.nodes), off, lane, q0, q1, q2, q3);
-    }
-#endif
     if (trav) {
       const bool leaf = (cur & REF_LEAF) != 0;
       const bool tri = leaf && (cur & REF_TRI);
-#if !MIRT_WF_QUAD_FETCH
       const uint32_t roff = cur << 4;
       const float4* rec = reinterpret_cast<const float4*>(reinterpret_cast<const unsigned char*>(a.nodes) + roff);
       const float4 q0 = rec[0];
       float4 q1 = make_float4(0, 0, 0, 0), q2 = q1, q3 = q1;
       if (!leaf || tri) { q1 = rec[1]; q2 = rec[2]; }
       if (!leaf) q3 = rec[3];
-#endif
       bool pop = false;
       if (leaf) {
         // intersect_leaf_primitives, bvh_traversal.cu:47-89
@@ -389,7 +375,7 @@ __global__ void __launch_bounds__(WBLOCK, MIRT_WF_WAVES_PER_SIMD) wf_trace_kerne
           const bool hit = triangle_hit(q0, q1, q2, o, d, t);
           if (closer_hit(hit, t, tbest, off16, refbest)) {
             tbest = t; refbest = cur;
-            if (shadow && tbest < limit) trav = false;      // any-hit exit (same boolean as draw.cu:347-352 / 365-370)
+            if (shadow && anyhit && tbest < limit) trav = false;      // any-hit exit (same boolean as draw.cu:347-352 / 365-370)
           }
         } else {
           if (COUNT) cn.sphere_tests++;
@@ -398,7 +384,7 @@ __global__ void __launch_bounds__(WBLOCK, MIRT_WF_WAVES_PER_SIMD) wf_trace_kerne
           const bool hit = sphere_hit(q0, o, d, t, tc_, tf_);
           if (closer_hit(hit, t, tbest, off16, refbest)) {
             tbest = t; refbest = cur;
-            if (shadow && tbest < limit) trav = false;
+            if (shadow && anyhit && tbest < limit) trav = false;
           }
         }
         pop = trav;

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Static look at the trace kernel's traversal loop: compiles render.hip to gfx950 assembly with the given extra defines
-and counts, per instruction class, what sits inside the depth-2 loop of trace_kernel<false,false> (spill traffic there
+and counts, per instruction class, what sits inside the depth-2 loop of trace_kernel<false, ...> (spill traffic there
 is what to watch: the kernel runs at the 128-VGPR edge and small source changes move spills in and out of the loop --
 a scratch reload of the lane's LDS stack address on every push and pop has cost 10-50 % more than once).
 
@@ -35,10 +35,10 @@ def _compile(defines):
     return _COMPILED[defines]
 
 
-def analyze(defines=(), kernel="trace_kernelILb0ELb0ELi8ELb1ELi6EE"):
+def analyze(defines=(), kernel="trace_kernelILb0ELi8ELb1ELi6EE"):
     """Returns (resources, counts, spills): the kernel's resource usage lines, instruction counts by class inside the
     traversal loop, and [(position, instruction)] of every spill instruction in it.  `kernel`: the mangled instantiation,
-    trace_kernel<COUNT, PROF, TABLES, QN, SPECX>: ...Li8ELb1ELi6EE = byte-indexed RNG tables, quantised nodes, no point lights /
+    trace_kernel<COUNT, TABLES, QN, SPECX>: ...Li8ELb1ELi6EE = byte-indexed RNG tables, quantised nodes, no point lights /
     transparency / gi (the headline scene's kernel); ...Li8ELb0ELi2EE = 64-byte node records (scenes with triangles), no point
     lights (redchair.txt); ...Li0EE: the general kernels."""
     remarks, asm = _compile(tuple(defines))
