@@ -242,7 +242,7 @@ class RawConfig:
         return st.as_dict()
 
     def set_option(self, name, value):
-        """mirt_scene_set_option: build options ("leaf_spheres", "bounds_as_shipped") take effect at the next build_lbvh_karas."""
+        """mirt_scene_set_option: the build option "bounds_as_shipped" takes effect at the next build_lbvh_karas, every other one at the next render."""
         _check(lib().mirt_scene_set_option(self._h, name.encode(), int(value)))
 
     def get_option(self, name):

@@ -33,20 +33,29 @@ void pack_mat(const MirtMaterials& m, float4* out)
   out[2] = make_float4(m.trans.b, m.ior, m.roughness, 0.0f);
 }
 
-struct OptionDesc { const char* name; int Options::*field; int lo, hi; };
+// mode: the option selects what is computed or visited (another tree, another walk, another render path) -- as opposed to a
+// tuning value, which only moves time
+struct OptionDesc { const char* name; int Options::*field; int lo, hi; bool mode; };
 const OptionDesc OPTIONS[] = {
-  {"bounds_as_shipped", &Options::bounds_as_shipped, 0, 1},
-  {"traversal", &Options::traversal, 0, 2}, {"wavefront", &Options::wavefront, 0, 1},
-  {"stack_lds_depth", &Options::stack_lds_depth, -1, 64}, {"refill_k", &Options::refill_k, 0, 64}, {"batch_k", &Options::batch_k, 1, 64},
-  {"leaf_k", &Options::leaf_k, 1, 64}, {"reps", &Options::reps, 1, 8}, {"drain_lanes", &Options::drain_lanes, 0, 64},
-  {"chunk_shift", &Options::chunk_shift, 0, 12}, {"trace_waves", &Options::trace_waves, 0, 1 << 20}, {"sched", &Options::sched, 0, 1}, {"qnodes", &Options::qnodes, 0, 1}, {"shadow_anyhit", &Options::shadow_anyhit, 0, 1}, {"skip_unlit", &Options::skip_unlit, 0, 1}, {"specialise", &Options::specialise, 0, 1}, {"slab_log2", &Options::slab_log2, 8, 30},
-  {"wf_pool", &Options::wf_pool, 256, 1 << 24}, {"wf_refill_k", &Options::wf_refill_k, 1, 64},
+  {"bounds_as_shipped", &Options::bounds_as_shipped, 0, 1, true},
+  {"traversal", &Options::traversal, 0, 2, true}, {"wavefront", &Options::wavefront, 0, 1, true},
+  {"qnodes", &Options::qnodes, 0, 1, true}, {"shadow_anyhit", &Options::shadow_anyhit, 0, 1, true}, {"skip_unlit", &Options::skip_unlit, 0, 1, true},
+  {"stack_lds_depth", &Options::stack_lds_depth, -1, 64, false}, {"refill_k", &Options::refill_k, 0, 64, false}, {"batch_k", &Options::batch_k, 1, 64, false},
+  {"leaf_k", &Options::leaf_k, 1, 64, false}, {"reps", &Options::reps, 1, 8, false}, {"drain_lanes", &Options::drain_lanes, 0, 64, false},
+  {"chunk_shift", &Options::chunk_shift, 0, 12, false}, {"trace_waves", &Options::trace_waves, 0, 1 << 20, false}, {"sched", &Options::sched, 0, 1, false},
+  {"specialise", &Options::specialise, 0, 1, false}, {"slab_log2", &Options::slab_log2, 8, 30, false},
+  {"wf_pool", &Options::wf_pool, 256, 1 << 24, false}, {"wf_refill_k", &Options::wf_refill_k, 1, 64, false},
 };
 
-// MIRT_<NAME> (upper case) overrides an option's default; read once per scene, here
+// MIRT_<NAME> (upper case) overrides an option's default; read once per scene, here.  Only the tuning values: a mode switch
+// (traversal = 2 changes pixels on triangle silhouettes) is set through mirt_scene_set_option, or from the environment when
+// MIRT_ALLOW_ENV=1 says that is meant (tools/ sweeps) -- a variable left over in a shell must not change an image.
 void options_from_env(Options& o)
 {
+  const char* allow = getenv("MIRT_ALLOW_ENV");
+  const bool modes = allow && atoi(allow) != 0;
   for (const OptionDesc& d : OPTIONS) {
+    if (d.mode && !modes) continue;
     std::string env = "MIRT_";
     for (const char* c = d.name; *c; ++c) env += (char)toupper(*c);
     if (const char* e = getenv(env.c_str())) { const long v = atol(e); if (v >= d.lo && v <= d.hi) o.*(d.field) = (int)v; }
@@ -54,6 +63,13 @@ void options_from_env(Options& o)
 }
 
 int scene_create(const MirtSceneDesc* d, int device, MirtScene** out);
+
+// mirt_get_stats: take a context's overflow count and zero it in one atomic step (a frame issued meanwhile from another host
+// thread keeps every increment: it lands either in this reading or in the next)
+__global__ void take_overflow_kernel(unsigned long long* counters)
+{
+  counters[10] = atomicExch(&counters[9], 0ull);
+}
 
 } // namespace
 
@@ -190,8 +206,8 @@ int scene_create(const MirtSceneDesc* d, int device, MirtScene** out)
   {
     const size_t nodes_bytes = N > 1 ? 64 * (size_t)(N - 1) : 0;
     const size_t sph_bytes = 16 * (size_t)sc->Ns, tri_bytes = 48 * (size_t)sc->Nt;
-    // (sphere-only scenes also get 32-byte quantised node records behind the primitives, scene_dev.h)
-    const size_t qnode_bytes = (sc->Nt == 0 && N > 1) ? 32 * (size_t)(N - 1) : 0;
+    // (32-byte quantised node records behind the primitives, scene_dev.h)
+    const size_t qnode_bytes = N > 1 ? 32 * (size_t)(N - 1) : 0;
     const size_t total = nodes_bytes + sph_bytes + tri_bytes + 64 + qnode_bytes;
     if (total > 0xfffffff0ull) { delete sc; set_error("mirt_scene_create: scene too large for 32-bit record offsets"); return MIRT_ERR_ARG; }
     hipError_t e = hipMalloc(&sc->heap, total);
@@ -213,7 +229,8 @@ int scene_create(const MirtSceneDesc* d, int device, MirtScene** out)
     alloc((void**)&sc->tris_before, 4 * ((size_t)N + 1));
   }
   alloc((void**)&sc->bounds_keys, 6 * 4);
-  alloc((void**)&sc->qparams, 6 * 4);
+  alloc((void**)&sc->qparams, 9 * 4);
+  alloc((void**)&sc->tri_boxes, 32 * (size_t)sc->Nt);
   for (int i = 0; i < mirt::MIRT_MAX_FRAMES; ++i) {
     alloc((void**)&sc->ctx[i].counters, 16 * sizeof(unsigned long long));
     if (rc == MIRT_OK && hipMemset(sc->ctx[i].counters, 0, 16 * sizeof(unsigned long long)) != hipSuccess) rc = MIRT_ERR_HIP;
@@ -247,7 +264,7 @@ void mirt_scene_destroy(MirtScene* sc)
   hipFree(sc->unit_prim); hipFree(sc->tris_before); hipFree(sc->range);
   hipFree(sc->planes); hipFree(sc->suns); hipFree(sc->bulbs);
   hipFree(sc->codes); hipFree(sc->order); hipFree(sc->child_l); hipFree(sc->child_r); hipFree(sc->parent); hipFree(sc->boxes); hipFree(sc->build_ws);
-  hipFree(sc->bounds_keys); hipFree(sc->qparams);
+  hipFree(sc->bounds_keys); hipFree(sc->qparams); hipFree(sc->tri_boxes);
   for (int i = 0; i < mirt::MIRT_MAX_FRAMES; ++i) {
     mirt::RenderCtx& c = sc->ctx[i];
     hipFree(c.samples); hipFree(c.stack_spill); hipFree(c.pending); hipFree(c.counters); hipFree(c.args_dev);
@@ -316,9 +333,11 @@ int mirt_get_stats(MirtScene* sc, MirtStats* out)
     if (c.used) {     // capacity overflows of the frames this context rendered since the previous call
       MIRT_HIP(hipEventSynchronize(c.ev3));
       unsigned long long ov = 0;
-      MIRT_HIP(hipMemcpy(&ov, c.counters + 9, sizeof(ov), hipMemcpyDeviceToHost));
+      hipLaunchKernelGGL(take_overflow_kernel, dim3(1), dim3(1), 0, c.stream, c.counters);
+      MIRT_HIP(hipGetLastError());
+      MIRT_HIP(hipStreamSynchronize(c.stream));
+      MIRT_HIP(hipMemcpy(&ov, c.counters + 10, sizeof(ov), hipMemcpyDeviceToHost));
       sc->overflow_events += ov;
-      MIRT_HIP(hipMemset(c.counters + 9, 0, sizeof(ov)));
     }
     if (c.used && !c.timed) {
       MIRT_HIP(hipEventSynchronize(c.ev3));
@@ -343,7 +362,7 @@ int mirt_get_stats(MirtScene* sc, MirtStats* out)
   out->overflow_events = sc->overflow_events;
   sc->overflow_events = 0;
   if (out->overflow_events) {
-    set_error("mirt_get_stats: capacity overflow during a render (traversal stack deeper than 64 entries or pending-ray list full): the image is missing contributions");
+    set_error("mirt_get_stats: capacity overflow during a render (the pending-children list of refraction / gi rays was full): the image is missing contributions");
     return MIRT_ERR_STATE;
   }
   return MIRT_OK;

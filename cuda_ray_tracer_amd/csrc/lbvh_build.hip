@@ -384,11 +384,13 @@ MIRT_DEV uint32_t make_ref(uint32_t node, uint32_t leaf_base, const uint32_t* __
   return 4u * node;
 }
 
-// Quantised node records for sphere-only scenes (scene_dev.h): child boxes on the scene-bounds grid, rounded outwards.
+// Quantised node records (scene_dev.h): child boxes on the scene-bounds grid, rounded outwards.
 MIRT_DEV uint32_t qlo(float x, float smin, float step) { const float q = floorf((x - smin) / step) - 1.0f; return (uint32_t)fminf(fmaxf(q, 0.0f), QGRID); }
 MIRT_DEV uint32_t qhi(float x, float smin, float step) { const float q = ceilf((x - smin) / step) + 1.0f; return (uint32_t)fminf(fmaxf(q, 0.0f), QGRID); }
 __global__ void __launch_bounds__(BLOCK) pack_qnodes_kernel(int n, const uint32_t* __restrict__ bkeys, const uint32_t* __restrict__ child_l,
                                                             const uint32_t* __restrict__ child_r, const float* __restrict__ boxes,
+                                                            const uint32_t* __restrict__ order, const MirtPrimRef* __restrict__ refs,
+                                                            const uint32_t* __restrict__ tris_before, const uint2* __restrict__ range,
                                                             uint4* __restrict__ qnodes, float* __restrict__ qparams, uint32_t qbase16, uint32_t prim_base16)
 {
   const int p = blockIdx.x * BLOCK + threadIdx.x;
@@ -399,19 +401,21 @@ __global__ void __launch_bounds__(BLOCK) pack_qnodes_kernel(int n, const uint32_
     const float range = key2f(bkeys[3 + k]) - smin[k];
     step[k] = range > 0.0f ? range / QGRID : 1.0f;
   }
-  if (p == 0) { for (int k = 0; k < 3; ++k) { qparams[k] = smin[k]; qparams[3 + k] = step[k]; } }
+  if (p == 0) { for (int k = 0; k < 3; ++k) { qparams[k] = smin[k]; qparams[3 + k] = step[k]; qparams[6 + k] = QINV_STEPS / step[k]; } }
   if (p >= n - 1) return;
   const uint32_t leaf_base = (uint32_t)(n - 1);
   const uint32_t c[2] = {child_l[p], child_r[p]};
   uint32_t w[8];
+  bool pure[2];
 #pragma unroll
   for (int s = 0; s < 2; ++s) {
     const float* b = boxes + 6 * (size_t)c[s];
 #pragma unroll
     for (int k = 0; k < 3; ++k) w[3 * s + k] = qlo(b[2 * k], smin[k], step[k]) | (qhi(b[2 * k + 1], smin[k], step[k]) << 16);
-    // (sphere-only scene: sorted leaf j's record is unit j of the primitive region)
-    w[6 + s] = c[s] >= leaf_base ? (REF_LEAF | (prim_base16 + (c[s] - leaf_base))) : (qbase16 + 2u * c[s]);
+    const uint32_t r = make_ref(c[s], leaf_base, order, refs, tris_before, range, prim_base16, &pure[s]);
+    w[6 + s] = c[s] >= leaf_base ? r : (qbase16 + 2u * c[s]);
   }
+  if (pure[0] && pure[1]) w[6] |= REF_QPURE;
   qnodes[2 * (size_t)p + 0] = make_uint4(w[0], w[1], w[2], w[3]);
   qnodes[2 * (size_t)p + 1] = make_uint4(w[4], w[5], w[6], w[7]);
 }
@@ -445,7 +449,7 @@ __global__ void __launch_bounds__(BLOCK) refit_pack_kernel(int n, const uint32_t
                                                            const uint32_t* __restrict__ child_l, const uint32_t* __restrict__ child_r,
                                                            const int* __restrict__ parent, uint32_t* __restrict__ arrived,
                                                            float* boxes, float4* __restrict__ nodes, const uint32_t* __restrict__ tris_before,
-                                                           const uint2* __restrict__ range, uint32_t prim_base16)
+                                                           const uint2* __restrict__ range, uint32_t prim_base16, float4* __restrict__ tri_boxes)
 {
   const int j = blockIdx.x * BLOCK + threadIdx.x;
   if (j >= n) return;
@@ -453,6 +457,10 @@ __global__ void __launch_bounds__(BLOCK) refit_pack_kernel(int n, const uint32_t
   uint32_t cur = leaf_base + (uint32_t)j;
   const MirtPrimRef r = refs[order[j]];
   const Box b = prim_box(r.type, r.id, spheres, tri_verts);
+  if (r.type != 0) {      // the triangle's exact leaf box, by scene index (the quantised walk's triangle check, render.hip)
+    tri_boxes[2 * (size_t)r.id + 0] = make_float4(b.xmin, b.xmax, b.ymin, b.ymax);
+    tri_boxes[2 * (size_t)r.id + 1] = make_float4(b.zmin, b.zmax, 0.0f, 0.0f);
+  }
   // Hand-off protocol (MI355X guide, "sc1 stores and loads on both sides"): every box word is written with a write-through
   // (agent-scope atomic) store and drained with s_waitcnt vmcnt(0) before the arrival counter is bumped; the second arriver
   // learns from the value its own add returned that the sibling's box is out, and reads it with L1-bypassing loads.
@@ -561,12 +569,12 @@ int build_lbvh(MirtScene* sc, hipStream_t stream)
   hipLaunchKernelGGL(scatter_prims_kernel, dim3(nblk), dim3(BLOCK), 0, stream, n, sc->order, sc->refs_in, sc->tris_before, sc->spheres, sc->tris,
                      reinterpret_cast<float4*>(sc->heap + sc->prim_base), sc->unit_prim);
   hipLaunchKernelGGL(refit_pack_kernel, dim3(nblk), dim3(BLOCK), 0, stream, n, sc->order, sc->refs_in, sc->spheres, sc->tri_verts,
-                     sc->child_l, sc->child_r, sc->parent, arrived, sc->boxes, sc->nodes, sc->tris_before, sc->range, sc->prim_base / 16u);
+                     sc->child_l, sc->child_r, sc->parent, arrived, sc->boxes, sc->nodes, sc->tris_before, sc->range, sc->prim_base / 16u, sc->tri_boxes);
   sc->root_ref_q = REF_NONE;
   if (sc->qnode_base && n > 1 && !sc->opt.bounds_as_shipped) {
     const int kblk = (n - 1 + BLOCK - 1) / BLOCK;
     hipLaunchKernelGGL(pack_qnodes_kernel, dim3(kblk), dim3(BLOCK), 0, stream, n, sc->bounds_keys, sc->child_l, sc->child_r, sc->boxes,
-                       reinterpret_cast<uint4*>(sc->heap + sc->qnode_base), sc->qparams, sc->qnode_base / 16u, sc->prim_base / 16u);
+                       sc->order, sc->refs_in, sc->tris_before, sc->range, reinterpret_cast<uint4*>(sc->heap + sc->qnode_base), sc->qparams, sc->qnode_base / 16u, sc->prim_base / 16u);
     sc->root_ref_q = sc->qnode_base / 16u;
   }
   MIRT_HIP(hipGetLastError());

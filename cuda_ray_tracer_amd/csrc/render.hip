@@ -49,12 +49,35 @@ constexpr int MAX_CHUNK_SHIFT = 8, MIN_CHUNK_SHIFT = 6;   // a wave takes 64..25
 #define MIRT_STACK_LDS 24
 #endif
 constexpr int STACK_LDS = MIRT_STACK_LDS;
-// QN: the scene's nodes are 32-byte quantised records (sphere-only scenes, scene_dev.h); SPECX: SPEC_NOBULB / SPEC_NOPEND of
-// shade_common.h (instantiated: both or none with QN; both, SPEC_NOBULB or none without)
+// The quantised walk found a triangle hit it is about to accept (scene_dev.h): does the reference's walk reach this leaf?  Yes,
+// provably, if the triangle's exact leaf box passes the order-independent clauses of hit_aabb_adapted (bvh_traversal.cu:11-44)
+// and the ray enters it before the hit: every ancestor's exact box contains the leaf box and the slab arithmetic is monotone in
+// the box planes, so t_enter(ancestor) <= t_enter(leaf) < t <= the best distance at the time the ancestor was tested, and each of
+// those tests passed.  A hit outside its box (the triangle test accepts up to 0.001 outside the triangle, struct.cu:155) does
+// not qualify: the ray is then walked again over the exact records.  Rare: the scene-sized arguments come through `ap`.
+MIRT_DEV bool triangle_leaf_reached(const RenderArgs* __restrict__ ap, uint32_t off16, const f3& o, const f3& d, float t, float tmin, f3& inv)
+{
+  const RenderArgs* aq = ap;
+  asm volatile("" : "+s"(aq));
+  const uint32_t id = aq->unit_prim[off16 - aq->prim_base16] & 0x7fffffffu;
+  const float4 b0 = aq->tri_boxes[2 * (size_t)id], b1 = aq->tri_boxes[2 * (size_t)id + 1];
+  inv = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+  const float tx1 = (b0.x - o.x) * inv.x, tx2 = (b0.y - o.x) * inv.x;
+  const float ty1 = (b0.z - o.y) * inv.y, ty2 = (b0.w - o.y) * inv.y;
+  const float tz1 = (b1.x - o.z) * inv.z, tz2 = (b1.y - o.z) * inv.z;
+  const float te = fmaxf(fmaxf(fminf(tx1, tx2), fminf(ty1, ty2)), fminf(tz1, tz2));
+  const float tx = fminf(fminf(fmaxf(tx1, tx2), fmaxf(ty1, ty2)), fmaxf(tz1, tz2));
+  return te < tx && tx > tmin && te < t;
+}
+
+// QN: the walk starts on the 32-byte quantised node records (scene_dev.h); SPECX: SPEC_NOTRI / SPEC_NOBULB / SPEC_NOPEND of
+// shade_common.h.  With QN and triangles a lane can also be on the 64-byte exact records (S.qsx == 0: its ray is being walked
+// again, triangle_leaf_reached); then S.inv holds 1 / d.
 template <bool COUNT, int TABLES, bool QN, int SPECX = 0>
 __global__ void __launch_bounds__(TRACE_BLOCK, MIRT_WAVES_PER_SIMD) trace_kernel(const RenderArgs* __restrict__ ap, const HotArgs h)
 {
-  constexpr int SPEC = (QN ? SPEC_NOTRI : 0) | SPECX;
+  constexpr int SPEC = SPECX;
+  constexpr bool NOTRI = (SPEC & SPEC_NOTRI) != 0;
   __shared__ __attribute__((aligned(16))) unsigned char lds_raw[STACK_LDS * TRACE_BLOCK * 4];     // traversal stacks: STACK_LDS x TRACE_BLOCK words
   // The random-number state (8 words per lane) is only touched in the shade phase: it lives here during traversal so
   // that it does not occupy registers across the hot loop (the kernel runs at the 128-VGPR edge of 4 waves per SIMD).
@@ -79,6 +102,9 @@ __global__ void __launch_bounds__(TRACE_BLOCK, MIRT_WAVES_PER_SIMD) trace_kernel
   unsigned long long c_next = 0, c_end = 0;   // wave-uniform: this wave's current chunk
   bool exhausted = false;                      // wave-uniform: the global counter has run past the frame
 
+#if MIRT_PF_PUSH
+  uint32_t pfv = 0;
+#endif
   Lane S;
   S.g = -1; S.trav = false;
   S.rng.v0 = S.rng.v1 = S.rng.v2 = S.rng.v3 = S.rng.v4 = S.rng.d = 0; S.rng.bm_flag = 0; S.rng.bm_extra = 0.0f;
@@ -200,7 +226,8 @@ __global__ void __launch_bounds__(TRACE_BLOCK, MIRT_WAVES_PER_SIMD) trace_kernel
           float t = 0.0f;
           bool hit = false;
           const float4 q0 = rec[0];
-          if (!QN && (S.cur & REF_TRI)) {      // (quantised nodes: a sphere-only scene)
+          const bool tri = !NOTRI && (S.cur & REF_TRI) != 0;
+          if (tri) {
             if (COUNT) cn.tri_tests++;
             const float4 q1 = rec[1], q2 = rec[2];
             hit = triangle_hit(q0, q1, q2, S.o, S.d, t);
@@ -208,10 +235,20 @@ __global__ void __launch_bounds__(TRACE_BLOCK, MIRT_WAVES_PER_SIMD) trace_kernel
             if (COUNT) cn.sphere_tests++;
             float tc, t_far;
             hit = sphere_hit(q0, S.o, S.d, t, tc, t_far);
-            if (QN && hit) hit = sphere_leaf_box_admits(q0, S.o, S.d, tc, t_far);
+            if (QN && hit && (NOTRI || S.qsx != 0u)) hit = sphere_leaf_box_admits(q0, S.o, S.d, tc, t_far);
           }
           // (S.trav is true here)
-          const bool closer = closer_hit(hit, t, S.tbest, S.cur & REF_OFFMASK, S.refbest);
+          bool closer = closer_hit(hit, t, S.tbest, S.cur & REF_OFFMASK, S.refbest);
+          if (QN && !NOTRI && closer && tri && S.qsx != 0u) {
+            f3 inv;
+            if (!triangle_leaf_reached(ap, S.cur & REF_OFFMASK, S.o, S.d, t, tmin, inv)) {
+              // walk this ray again from the root, over the exact records (node 0 sits at heap offset 0)
+              closer = false;
+              S.inv = inv; S.qsx = 0u;
+              S.tos = 0u; S.sp = 1;      // (the pop below makes the root the current node)
+              S.tbest = INFINITY; S.refbest = REF_NONE;
+            }
+          }
           S.tbest = closer ? t : S.tbest;
           S.refbest = closer ? S.cur : S.refbest;
           S.trav = !(closer && S.shadow && t < S.limit);      // any-hit exit
@@ -227,13 +264,13 @@ __global__ void __launch_bounds__(TRACE_BLOCK, MIRT_WAVES_PER_SIMD) trace_kernel
           bool hl, hr;
           float tel, ter;
           uint32_t lref, rref;
-          if (QN) {
-            // two 16-byte requests: twelve grid coordinates and the child references; every node of a sphere-only scene may
-            // be descended near child first
+          if (QN && (NOTRI || S.qsx != 0u)) {
+            // two 16-byte requests: twelve grid coordinates and the child references (REF_QPURE on the first one: both subtrees
+            // hold spheres only -- every node of a sphere-only scene)
             const uint4 w0 = *reinterpret_cast<const uint4*>(nrec), w1 = *reinterpret_cast<const uint4*>(nrec + 1);
             box_pair_q(w0, w1.x, w1.y, S.inv, S.qb, S.qc, S.qsx, S.qsy, S.qsz, S.tbest, tmin, hl, hr, tel, ter);
             lref = w1.z; rref = w1.w;
-            order_children(hl, hr, tel, ter, NODE_SWAP_ANY | NODE_SWAP_PURE, h.swap_mask, lref, rref);
+            order_children(hl, hr, tel, ter, NOTRI ? (NODE_SWAP_ANY | NODE_SWAP_PURE) : (NODE_SWAP_ANY | ((w1.z >> 29) & 1u)), h.swap_mask, lref, rref);
           } else {
             const float4 q0 = nrec[0], q1 = nrec[1], q2 = nrec[2];
             const uint4 ch = *reinterpret_cast<const uint4*>(nrec + 3);      // child references, NODE_SWAP_* flags
@@ -241,6 +278,9 @@ __global__ void __launch_bounds__(TRACE_BLOCK, MIRT_WAVES_PER_SIMD) trace_kernel
             lref = ch.x; rref = ch.y;
             order_children(hl, hr, tel, ter, ch.z, h.swap_mask, lref, rref);
           }
+#if MIRT_PF_PUSH
+          asm volatile("" :: "v"(pfv));
+#endif
           // first child next, push the second (bvh_traversal.cu:149-157: left, right), written with selects: one short
           // branch for the push
           const bool both = hl && hr;
@@ -256,6 +296,9 @@ __global__ void __launch_bounds__(TRACE_BLOCK, MIRT_WAVES_PER_SIMD) trace_kernel
             else h.stack_spill[(size_t)(S.sp - h.lds_depth) * gthreads + gid] = S.tos;
             S.tos = rref;
             ++S.sp;
+#if MIRT_PF_PUSH
+            pfv = *reinterpret_cast<const uint32_t*>(heap + (rref << 4));      // experiment: touch the pushed sibling's record
+#endif
             if (COUNT) cn.max_stack = max(cn.max_stack, (uint32_t)S.sp);
           }
           S.cur = hl ? lref : (hr ? rref : S.cur);
@@ -635,12 +678,14 @@ static int render_impl(MirtScene* sc, const MirtRenderParams* p, void* d_rgba8, 
   a.stripe_rows = p->stripe_rows; a.num_parts = p->num_parts; a.part = p->part;
   a.sample_first = sample_first; a.sample_count = sample_count; a.seed_per_pixel = per_pixel_seed ? 1 : 0;
   a.nodes = sc->nodes; a.unit_prim = sc->unit_prim; a.mats = sc->mats;
-  // quantised node records: sphere-only scenes, single-kernel path, any order but the reference's own
+  // quantised node records: single-kernel path, any order but the reference's own
   const bool qn = sc->root_ref_q != REF_NONE && opt.qnodes != 0 && opt.traversal >= 1 && opt.wavefront == 0;
+  const bool notri = sc->Nt == 0;
   // kernels specialised for what the scene does not have (SPEC_*, shade_common.h)
   const bool nobulb = opt.specialise != 0 && sc->d.num_bulbs == 0, nopend = opt.specialise != 0 && !need_pending;
   a.root_ref = qn ? sc->root_ref_q : sc->root_ref; a.num_spheres = sc->Ns; a.num_prims = sc->N;
   a.qparams = qn ? sc->qparams : nullptr;
+  a.tri_boxes = sc->tri_boxes;
   a.prim_base16 = sc->prim_base / 16u;
   a.swap_mask = opt.traversal == 1 ? NODE_SWAP_PURE : (opt.traversal == 2 ? NODE_SWAP_ANY : 0u);
   a.skip_unlit = (opt.skip_unlit != 0 && sc->colors_finite && sc->d.num_suns + sc->d.num_bulbs <= 32) ? 1 : 0;
@@ -738,11 +783,14 @@ static int render_impl(MirtScene* sc, const MirtRenderParams* p, void* d_rgba8, 
         const bool t8 = a.needs_rng && a.rng.mode == 0 && a.rng.chunk_bits == 8;
 #define MIRT_LAUNCH(C, T, Q, P) hipLaunchKernelGGL((trace_kernel<C, T, Q, P>), dim3(blocks), dim3(TRACE_BLOCK), 0, stream, adev, h)
 #define MIRT_LAUNCH_T(C, Q, P) do { if (t8) MIRT_LAUNCH(C, 8, Q, P); else MIRT_LAUNCH(C, 4, Q, P); } while (0)
-#define MIRT_LAUNCH_Q(C) do { if (qn && nobulb && nopend) MIRT_LAUNCH_T(C, true, SPEC_NOBULB | SPEC_NOPEND); else if (qn) MIRT_LAUNCH_T(C, true, 0); \
-                              else if (nobulb && nopend) MIRT_LAUNCH_T(C, false, SPEC_NOBULB | SPEC_NOPEND); \
-                              else if (nobulb) MIRT_LAUNCH_T(C, false, SPEC_NOBULB); else MIRT_LAUNCH_T(C, false, 0); } while (0)
+#define MIRT_LAUNCH_S(C, Q) do { if (nobulb && nopend) MIRT_LAUNCH_T(C, Q, SPEC_NOBULB | SPEC_NOPEND); else if (nobulb) MIRT_LAUNCH_T(C, Q, SPEC_NOBULB); \
+                                 else MIRT_LAUNCH_T(C, Q, 0); } while (0)
+#define MIRT_LAUNCH_Q(C) do { if (qn && notri && nobulb && nopend) MIRT_LAUNCH_T(C, true, SPEC_NOTRI | SPEC_NOBULB | SPEC_NOPEND); \
+                              else if (qn && notri) MIRT_LAUNCH_T(C, true, SPEC_NOTRI); \
+                              else if (qn) MIRT_LAUNCH_S(C, true); else MIRT_LAUNCH_S(C, false); } while (0)
         if (count) MIRT_LAUNCH_Q(true); else MIRT_LAUNCH_Q(false);
 #undef MIRT_LAUNCH_Q
+#undef MIRT_LAUNCH_S
 #undef MIRT_LAUNCH_T
 #undef MIRT_LAUNCH
       }

@@ -22,14 +22,19 @@ constexpr uint32_t REF_LEAF = 0x80000000u;
 constexpr uint32_t REF_TRI = 0x40000000u;
 constexpr uint32_t REF_OFFMASK = 0x0fffffffu;  // the record's offset in the heap, in 16-byte units: `ref << 4` is its byte offset (the shift drops the flags)
 constexpr uint32_t REF_NONE = 0xf0000000u;   // no record (bits 29..28 are set in no real reference; offset bits 0)
-// Quantised node records (sphere-only scenes, option "qnodes"): 32 bytes instead of 64, i.e. two 16-byte requests per node
-// visit instead of four -- the address units are what bounds the trace kernel.  Both child boxes as 12 x uint16 on the
-// scene-bounds grid (65535 steps per axis, rounded outwards by one more step), then the two child references.  The boxes are
-// supersets of the exact ones: for spheres the closest hit cannot change (shade_common.h, sphere_leaf_box_admits restores the
-// one clause of the reference's box test that a larger box weakens); the visit counters do (+0.13 % node visits on the bundled scenes).
+// Quantised node records (option "qnodes"): 32 bytes instead of 64, i.e. two 16-byte requests per node visit instead of four
+// and half the bytes -- the address units bound the trace kernel on the bundled scenes, memory on the 2 M-primitive one.  Both
+// child boxes as 12 x uint16 on the scene-bounds grid (65535 steps per axis, rounded outwards by one more step), then the two
+// child references.  The boxes are supersets of the exact ones, so the walk visits a superset of the reference's nodes in the
+// same order.  For spheres the closest hit cannot change (shade_common.h, sphere_leaf_box_admits restores the one clause of the
+// reference's box test that a larger box weakens).  A triangle hit is accepted only if the reference's walk provably reaches
+// that leaf (triangle_leaf_reached, render.hip); otherwise the ray is walked again over the 64-byte exact records.
 //   words 0..2 child 0: (xmin | xmax << 16), (ymin | ymax << 16), (zmin | zmax << 16); words 3..5 child 1; 6, 7: references
+//   (bit 29 of word 6, REF_QPURE: both subtrees of this node hold spheres only -- NODE_SWAP_PURE of the 64-byte record)
 // Node i sits at heap offset qnode_base + 32 i: its reference is qnode_base / 16 + 2 i.
 constexpr float QGRID = 65535.0f;
+constexpr uint32_t REF_QPURE = 0x20000000u;
+constexpr float QINV_STEPS = 1152921504606846976.0f;   // 2^60: |1 / d| is clamped to this many grid steps per unit of t (quantised_axis)
 // node record word 14 (after the two child references): which descent orders the node allows
 constexpr uint32_t NODE_SWAP_PURE = 1u;       // both subtrees hold spheres only: near-child-first cannot change the closest hit
 constexpr uint32_t NODE_SWAP_ANY = 2u;        // always set (the mask of MIRT_TRAVERSAL_ORDERED_ALL)
@@ -64,7 +69,8 @@ struct RenderArgs {
   uint32_t swap_mask;             // NODE_SWAP_* bits that allow near-child-first descent (0: the reference's left-first order)
   int skip_unlit;                 // 1: shadow rays towards lights the shading normal faces away from are not traced (all colours finite)
   int shadow_anyhit;              // 1: a shadow ray ends at its first occluder; 0: nearest-hit query like every other ray (draw.cu:347-352)
-  const float* qparams;           // quantised nodes in use: grid origin xyz, grid step xyz (else null)
+  const float* qparams;           // quantised nodes in use: grid origin xyz, grid step xyz, 2^60 / grid step xyz (else null)
+  const float4* tri_boxes;        // 2 x float4 per triangle (scene order): its exact leaf box (xmin, xmax, ymin, ymax) (zmin, zmax, -, -)
   int num_spheres;
   int num_prims;
   const PlaneDev* planes; int num_planes;
@@ -207,7 +213,8 @@ struct MirtScene {
   uint2* range = nullptr;               // [N - 1]: sorted-leaf range (first, last) of every internal node
   uint32_t qnode_base = 0;              // byte offset of the quantised node records in the heap (0: none built)
   uint32_t root_ref_q = mirt::REF_NONE; // root reference into the quantised records
-  float* qparams = nullptr;             // [6] device: grid origin, grid step
+  float* qparams = nullptr;             // [9] device: grid origin, grid step, 2^60 / grid step
+  float4* tri_boxes = nullptr;          // [2 Nt]: exact leaf box of every triangle (scene order), for the quantised walk's triangle check
   uint32_t* build_ws = nullptr; size_t build_ws_words = 0;   // LBVH build workspace (sort buffers, histograms, arrival counters)
   uint32_t* bounds_keys = nullptr;      // [6] ordered-uint min xyz, max xyz
   uint32_t root_ref = mirt::REF_NONE;

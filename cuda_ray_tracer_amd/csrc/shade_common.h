@@ -139,8 +139,7 @@ MIRT_DEV void box_pair(const float4 q0, const float4 q1, const float4 q2, float 
 //   pairs: the moves eat the saving and push spills into the loop, measured twice.)
 // * The near planes use the offset Cn, the far planes Cf: quantised_axis moves Cn down and Cf up by a bound on every rounding
 //   error on the way, so that the box the kernel tests contains the grid box for any ray origin, however far from the scene
-//   (origins on an infinite plane are).  A zero direction component gives NaN parameters, which fminf / fmaxf drop: the axis
-//   is then ignored -- a superset, like the outward rounding of the boxes themselves.
+//   (origins on an infinite plane are).
 MIRT_DEV void box_pair_q(const uint4 w0, const uint32_t w4, const uint32_t w5, const f3& A, const f3& Cn, const f3& Cf, uint32_t sx, uint32_t sy, uint32_t sz,
                          float tbest, float tmin, bool& hl, bool& hr, float& tel, float& ter)
 {
@@ -170,14 +169,18 @@ MIRT_DEV void box_pair_q(const uint4 w0, const uint32_t w4, const uint32_t w5, c
 // q * A + B; the margin E = 2^-20 |B| + 1.0625 |A| exceeds every rounding on the way: of A, of B and of the final fused
 // multiply-add (2^-21 (|B| + 65535 |A|) covers those with room to spare), of C0 and of C0 -+ E (each at most
 // 2^-24 |B| + |A| / 2, half an ulp of a number near 2^23 |A|).  The tested box is the grid box grown by about one more grid
-// step.  (2^23 |A| must not overflow, or a far plane at -inf would cull the box: such an axis -- a direction component
-// below 1e-25 or so -- gets NaN offsets and is ignored like a zero one.)
-MIRT_DEV void quantised_axis(float gmin, float gstep, float o, float inv, float& A, float& Cn, float& Cf, uint32_t& sel)
+// step.
+// A direction component of (nearly) zero -- 1 / d infinite, or so large that 2^23 A would overflow -- has its reciprocal
+// clamped to +-`lim` = 2^60 grid steps per unit of t: the axis becomes that of a ray needing 2^-60 of t per grid step, far
+// beyond any distance of a scene, and stays a proper slab test: a box whose slab the origin is not in is culled, as
+// (plane - o) * inf does in hit_aabb_adapted (bvh_traversal.cu:11-44); all of the accounting above is linear in A.  (Rounds
+// 1-2 ignored such an axis, a superset too, but every shadow ray of redchair.txt's `sun 0 1 2` then tested two axes only.)
+MIRT_DEV void quantised_axis(float gmin, float gstep, float lim, float o, float inv, float& A, float& Cn, float& Cf, uint32_t& sel)
 {
-  const float B = (gmin - o) * inv;
-  A = gstep * inv;
-  const float hA = fabsf(A) < 1e30f ? 1.0625f * fabsf(A) : __builtin_nanf("");
-  const float E = __builtin_fmaf(fabsf(B), 9.5367431640625e-07f, hA);
+  const float ic = fminf(fmaxf(inv, -lim), lim);
+  const float B = (gmin - o) * ic;
+  A = gstep * ic;
+  const float E = __builtin_fmaf(fabsf(B), 9.5367431640625e-07f, 1.0625f * fabsf(A));
   const float C0 = __builtin_fmaf(-8388608.0f, A, B);
   Cn = C0 - E;
   Cf = C0 + E;
@@ -310,9 +313,9 @@ MIRT_DEV void start_ray(const Args& a, Lane& S, Counters& cn)
     typedef const float __attribute__((address_space(4))) * ConstF;
     const ConstF qp = (ConstF)(unsigned long long)a.qparams;
     f3 A;
-    quantised_axis(qp[0], qp[3], S.o.x, S.inv.x, A.x, S.qb.x, S.qc.x, S.qsx);
-    quantised_axis(qp[1], qp[4], S.o.y, S.inv.y, A.y, S.qb.y, S.qc.y, S.qsy);
-    quantised_axis(qp[2], qp[5], S.o.z, S.inv.z, A.z, S.qb.z, S.qc.z, S.qsz);
+    quantised_axis(qp[0], qp[3], qp[6], S.o.x, S.inv.x, A.x, S.qb.x, S.qc.x, S.qsx);
+    quantised_axis(qp[1], qp[4], qp[7], S.o.y, S.inv.y, A.y, S.qb.y, S.qc.y, S.qsy);
+    quantised_axis(qp[2], qp[5], qp[8], S.o.z, S.inv.z, A.z, S.qb.z, S.qc.z, S.qsz);
     S.inv = A;
   }
   float tplane = INFINITY;

@@ -197,7 +197,8 @@ typedef struct MirtStats {
   float trace_kernel_ms_mean;
   int32_t frames_timed;
 } MirtStats;
-/* Waits for every frame in flight, then reports (and resets the running mean).  Up to four frames may be in flight on
+/* Waits for every frame in flight, then reports (and resets the running mean).  mirt_render / mirt_render_accumulate never
+ * report a capacity overflow themselves (they are asynchronous): poll this call after a render, or before using its image.  Up to four frames may be in flight on
  * different streams: a scene keeps four sets of render workspaces and reuses one only when its frame has finished. */
 int mirt_get_stats(MirtScene* sc, MirtStats* out);
 

@@ -71,7 +71,7 @@ typedef struct {
 
 typedef struct {
   uint64_t samples, rays, shadow_rays, node_iters, internal_visits, sphere_tests, tri_tests,
-           mat_fetches, max_stack, prim_hits, overflow;
+           mat_fetches, max_stack, prim_hits, overflow, qn_retraces;
 } OStats;
 
 typedef struct {
@@ -97,10 +97,17 @@ typedef struct {
  * does this when every colour is finite): the light's term is colour * light * max(dot, 0) = 0 whether it is occluded
  * or not (draw.cu:353-357, 371-374).  The ray still counts as a ray; it visits no node. */
 #define ORC_FLAG_SKIP_UNLIT    16u
-/* Quantised node records (the product's single-kernel path on sphere-only scenes, scene_dev.h): child boxes on the 65535-step
- * grid of the scene bounds, rounded outwards, tested with one fused multiply-add per plane; a sphere hit then has to pass the
+/* Quantised node records (the product's single-kernel path, scene_dev.h): child boxes on the 65535-step grid of the scene
+ * bounds, rounded outwards, tested with one fused multiply-add per plane; a sphere hit then has to pass the
  * `t_enter < t_exit && t_exit > t_min` clauses of its exact leaf box (bvh_traversal.cu:43), which the larger boxes weaken.
- * Same closest hit as the exact boxes; more node visits.  Only meaningful with ORDERED / ORDERED_ALL and without triangles. */
+ * Same closest hit as the exact boxes; more node visits.  Only meaningful with ORDERED / ORDERED_ALL.
+ * Triangles: the reference accepts hits up to 0.001 (barycentric) outside a triangle, possibly outside its box, and then
+ * whether the hit is found depends on which exact boxes culled the way to it.  A triangle hit that is about to be accepted
+ * is therefore checked against its exact leaf box (bvh_traversal.cu:11-44): if the box passes its order-independent clauses
+ * and the ray enters it before the hit (t_enter < t), every exact ancestor box -- each contains the leaf box, and the slab
+ * arithmetic is monotone in the box planes -- passes too with the best distance of its time (t_enter_ancestor <= t_enter <
+ * t <= t_max then), so the reference's walk reaches this leaf and finds the same hit.  Otherwise the ray is walked AGAIN from
+ * the root over the exact boxes (same order flags): rare (triangle silhouettes), exact. */
 #define ORC_FLAG_QNODES        32u
 #define ORC_FLAG_ORDERED       4u
 #define ORC_FLAG_ORDERED_ALL   8u   /* near child first at every node (triangle silhouettes may differ from the reference order) */
@@ -683,9 +690,16 @@ struct QAxis { float A, Cn, Cf; bool low_near; };
 static inline QAxis quantised_axis(float gmin, float gstep, float o, float inv)
 {
   QAxis a;
-  const float B = (gmin - o) * inv;
-  a.A = gstep * inv;
-  const float hA = fabsf(a.A) < 1e30f ? 1.0625f * fabsf(a.A) : NAN;
+  /* A direction component of (nearly) zero: 1 / d is infinite or so large that 2^23 A would overflow.  The reciprocal is clamped
+   * to +-2^60 grid steps per unit of t, i.e. the axis is treated as that of a ray which needs 2^-60 of t per grid step: far
+   * beyond any distance a scene has, and still a proper slab test -- a box whose slab the origin is not in is culled, as
+   * (plane - o) * inf does in hit_aabb_adapted (bvh_traversal.cu:11-44).  (Until round 3 such an axis was ignored, which made
+   * every shadow ray of redchair.txt's `sun 0 1 2` test two axes only.) */
+  const float lim = 1152921504606846976.0f / gstep;
+  const float ic = fminf(fmaxf(inv, -lim), lim);
+  const float B = (gmin - o) * ic;
+  a.A = gstep * ic;
+  const float hA = 1.0625f * fabsf(a.A);
   const float E = fmaf(fabsf(B), 9.5367431640625e-07f, hA);
   const float C0 = fmaf(-8388608.0f, a.A, B);
   a.Cn = C0 - E;
@@ -711,7 +725,7 @@ static inline bool hit_qbox(const ONode& b, const float* smin, const float* step
 
 /* traverse() with the product's near-child-first descent (see ORC_FLAG_ORDERED above): same closest hit as traverse(),
  * fewer node visits. */
-static Obj traverse_ordered(Ctx& cx, const Ray& ray, float initial_t_max, bool early, float stop_below)
+static Obj traverse_ordered(Ctx& cx, const Ray& ray, float initial_t_max, bool early, float stop_below, bool allow_qn = true)
 {
   const Scene& sc = *cx.sc;
   const bool order_pure = (cx.flags & (ORC_FLAG_ORDERED | ORC_FLAG_ORDERED_ALL)) != 0, order_all = (cx.flags & ORC_FLAG_ORDERED_ALL) != 0;
@@ -727,7 +741,7 @@ static Obj traverse_ordered(Ctx& cx, const Ray& ray, float initial_t_max, bool e
   uint32_t stack[64];
   int sp = 0;
   uint32_t cur = 0;
-  const bool qn = (cx.flags & ORC_FLAG_QNODES) != 0 && N > 1;      /* (a single primitive has no node records) */
+  const bool qn = allow_qn && (cx.flags & ORC_FLAG_QNODES) != 0 && N > 1;      /* (a single primitive has no node records) */
   float qstep[3];
   for (int k = 0; k < 3; ++k) { float range = sc.smax[k] - sc.smin[k]; qstep[k] = range > 0.0f ? range / 65535.0f : 1.0f; }
   const QAxis qax[3] = {quantised_axis(sc.smin[0], qstep[0], ray.eye.x, inv.x), quantised_axis(sc.smin[1], qstep[1], ray.eye.y, inv.y),
@@ -753,6 +767,11 @@ static Obj traverse_ordered(Ctx& cx, const Ray& ray, float initial_t_max, bool e
       }
       else { h = check_triangle(cx, ray, ref.id); cx.st.tri_tests++; }
       if (h.isHit && h.distance > 1e-6f && (h.distance < tmax || (have && h.distance == tmax && k < best_leaf))) {
+        if (qn && ref.type != 0) {      /* would the reference's walk have reached this triangle? (ORC_FLAG_QNODES above) */
+          float te;
+          const bool box_ok = hit_aabb_t(node, ray.eye, inv, tmin, INFINITY, &te);      /* t_enter < t_exit && t_exit > t_min */
+          if (!(box_ok && te < h.distance)) { cx.st.qn_retraces++; return traverse_ordered(cx, ray, initial_t_max, early, stop_below, false); }
+        }
         tmax = h.distance; best = h; best_leaf = k; have = true;
         if (early && best.distance < stop_below) return best;
       }
@@ -1092,7 +1111,7 @@ static void stats_add(OStats* a, const OStats& b)
 {
   a->samples += b.samples; a->rays += b.rays; a->shadow_rays += b.shadow_rays; a->node_iters += b.node_iters;
   a->internal_visits += b.internal_visits; a->sphere_tests += b.sphere_tests; a->tri_tests += b.tri_tests;
-  a->mat_fetches += b.mat_fetches; a->prim_hits += b.prim_hits; a->overflow += b.overflow;
+  a->mat_fetches += b.mat_fetches; a->prim_hits += b.prim_hits; a->overflow += b.overflow; a->qn_retraces += b.qn_retraces;
   if (b.max_stack > a->max_stack) a->max_stack = b.max_stack;
 }
 

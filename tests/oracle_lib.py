@@ -15,15 +15,20 @@ FLAG_ORDERED_ALL = 8    # near child first everywhere
 FLAG_SKIP_UNLIT = 16    # shadow rays towards lights the shading normal faces away from are not traced (their term is 0)
 # what libmirt does: any-hit shadow rays and no shadow rays to unlit lights, always; ordered traversal
 # where pixels cannot change, by default -- the oracle mirrors each so that the visit counters can be compared with ==
-FLAG_QNODES = 32        # quantised node records (sphere-only scenes, single-kernel path, traversal >= 1)
-PRODUCT_ALWAYS = FLAG_ANYHIT_SHADOW | FLAG_SKIP_UNLIT
-PRODUCT_FLAGS = PRODUCT_ALWAYS | FLAG_ORDERED
+FLAG_QNODES = 32        # quantised node records (single-kernel path, traversal >= 1; triangle hits outside their exact leaf box re-walk the exact boxes)
+PRODUCT_ALWAYS = FLAG_ANYHIT_SHADOW | FLAG_SKIP_UNLIT      # (the defaults of the scene options shadow_anyhit / skip_unlit)
+PRODUCT_FLAGS = PRODUCT_ALWAYS | FLAG_ORDERED | FLAG_QNODES   # default options, single-kernel path, more than one primitive
+REFERENCE_WALK = 0      # {traversal: 0, shadow_anyhit: 0, skip_unlit: 0, qnodes: 0}: draw.cu:292-377 + bvh_traversal.cu:92-183 verbatim
 
 
-def product_flags(scene_has_triangles, traversal=1, wavefront=False, qnodes=True):
-    """The oracle flags that mirror what libmirt does for a scene and option set (for counters to compare with ==)."""
-    f = PRODUCT_ALWAYS | {0: 0, 1: FLAG_ORDERED, 2: FLAG_ORDERED_ALL}[traversal]
-    if qnodes and not scene_has_triangles and traversal >= 1 and not wavefront:
+def product_flags(scene_has_triangles=False, traversal=1, wavefront=False, qnodes=True, shadow_anyhit=True, skip_unlit=True):
+    """The oracle flags that mirror what libmirt does for an option set (for counters to compare with ==)."""
+    f = {0: 0, 1: FLAG_ORDERED, 2: FLAG_ORDERED_ALL}[traversal]
+    if shadow_anyhit:
+        f |= FLAG_ANYHIT_SHADOW
+    if skip_unlit:
+        f |= FLAG_SKIP_UNLIT
+    if qnodes and traversal >= 1 and not wavefront:
         f |= FLAG_QNODES
     return f
 
@@ -50,7 +55,7 @@ NODE = np.dtype([("xmin", "<f4"), ("xmax", "<f4"), ("ymin", "<f4"), ("ymax", "<f
                  ("left", "<u4"), ("right", "<u4"), ("prim_offset", "<u4"), ("count", "<u4")])
 HIT = np.dtype([("t", "<f4"), ("kind", "<u4"), ("id", "<u4"), ("n", "<f4", 3)])
 STAT_FIELDS = ["samples", "rays", "shadow_rays", "node_iters", "internal_visits", "sphere_tests", "tri_tests",
-               "mat_fetches", "max_stack", "prim_hits", "overflow"]
+               "mat_fetches", "max_stack", "prim_hits", "overflow", "qn_retraces"]
 
 
 class Stats(C.Structure):

@@ -198,7 +198,7 @@ def test_config5_ordered_everywhere_gives_the_same_bytes_on_this_scene():
     assert np.array_equal(a8, b8) and np.array_equal(af.view(np.uint32), bf.view(np.uint32))
     assert sa["rays"] == sb["rays"] and sb["internal_visits"] < 0.5 * sa["internal_visits"]
     o = ol.OracleScene(ol.ArrayScene(stl), bounds_mode=0)
-    ref = o.render(w, h, spp, tile=(0, part, w, rows), flags=ol.PRODUCT_ALWAYS | ol.FLAG_ORDERED_ALL, nthreads=8)
+    ref = o.render(w, h, spp, tile=(0, part, w, rows), flags=ol.product_flags(traversal=2), nthreads=8)
     n = w * rows
     check_image(b8[:n], bf[:n], ref)
     rawc = m.initRawConfigFromStl(stl, 0)          # counters of the first row alone, against the oracle
@@ -290,6 +290,47 @@ def test_every_traversal_mode_matches_its_oracle_mirror(name, w, h, spp, travers
     check_image(gu8, gf, ref)
     for k in COUNTER_KEYS:
         assert st[k] == ref["stats"][k], (k, st[k], ref["stats"][k])
+
+
+REFERENCE_WALK = dict(traversal=0, shadow_anyhit=0, skip_unlit=0, qnodes=0)
+
+
+@pytest.mark.parametrize("name,w,h,spp,rays_per_sample,iters,leaf", [
+    ("tenthousand", 240, 135, 1, 5.49, 27.5, 1.86), ("spiral", 240, 135, 1, 9.43, 57.6, 14.36), ("redchair", 240, 135, 1, 6.18, 18.0, 2.55),
+    ("tri", 256, 256, 0, 1.31, 4.0, 1.03)])
+def test_reference_walk_mode_is_the_plain_restatement_counter_for_counter(name, w, h, spp, rays_per_sample, iters, leaf, gpu_scenes, oracle_scenes):
+    """One direct link from the HIP path to the reference's walk: with {traversal: 0, shadow_anyhit: 0, skip_unlit: 0,
+    qnodes: 0} the kernel is draw.cu:292-377 + bvh_traversal.cu:92-183 as written -- left child first, every shadow ray traced
+    to its nearest hit, every light's shadow ray traced, 64-byte exact boxes -- and is compared with the oracle's plain
+    restatement (flags = 0): pixels within 1e-4, every ray / node / primitive counter with ==.  The same counters reproduce the
+    statistics SURVEY.md Appendix G measured on the reference's own code (stub RNG there: 2 %; a node-loop iteration of
+    bvh_traversal.cu:107 is an internal visit or a leaf test)."""
+    stl, raw = gpu_scenes(name)
+    with options(raw, **REFERENCE_WALK):
+        gu8, gf = gpu_render(raw, w, h, spp, counters=True)
+        st = raw.stats()
+    ref = oracle_scenes(name).render(w, h, spp, flags=ol.REFERENCE_WALK, nthreads=8)
+    check_image(gu8, gf, ref)
+    for k in COUNTER_KEYS:
+        assert st[k] == ref["stats"][k], (k, st[k], ref["stats"][k])
+    assert abs(st["rays"] / st["samples"] / rays_per_sample - 1) < 0.02
+    assert abs((st["internal_visits"] + st["sphere_tests"] + st["tri_tests"]) / st["rays"] / iters - 1) < 0.02
+    assert abs((st["sphere_tests"] + st["tri_tests"]) / st["rays"] / leaf - 1) < 0.02
+
+
+@pytest.mark.parametrize("name", ["tenthousand", "redchair"])
+def test_default_mode_gives_the_bytes_of_the_reference_walk_mode(name, gpu_scenes):
+    """... and the default options (near child first, any-hit shadow rays, unlit lights skipped, quantised records) give the bytes
+    of that mode, float image included, with a fraction of the node visits: 1920x1080 x 16 spp."""
+    stl, raw = gpu_scenes(name)
+    w, h, spp = 1920, 1080, 16
+    a8, af = gpu_render(raw, w, h, spp, counters=True)
+    sa = raw.stats()
+    with options(raw, **REFERENCE_WALK):
+        b8, bf = gpu_render(raw, w, h, spp, counters=True)
+        sb = raw.stats()
+    assert np.array_equal(a8, b8) and np.array_equal(af.view(np.uint32), bf.view(np.uint32))
+    assert sa["rays"] == sb["rays"] and sa["internal_visits"] < 0.9 * sb["internal_visits"]
 
 
 @pytest.mark.parametrize("name", ["tenthousand", "spiral", "redchair", "tri"])

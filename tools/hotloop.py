@@ -35,7 +35,7 @@ def _compile(defines):
     return _COMPILED[defines]
 
 
-def analyze(defines=(), kernel="trace_kernelILb0ELi8ELb1ELi6EE"):
+def analyze(defines=(), kernel="trace_kernelILb0ELi8ELb1ELi7EE"):
     """Returns (resources, counts, spills): the kernel's resource usage lines, instruction counts by class inside the
     traversal loop, and [(position, instruction)] of every spill instruction in it.  `kernel`: the mangled instantiation,
     trace_kernel<COUNT, TABLES, QN, SPECX>: ...Li8ELb1ELi6EE = byte-indexed RNG tables, quantised nodes, no point lights /
