@@ -39,7 +39,7 @@ struct OptionDesc { const char* name; int Options::*field; int lo, hi; bool mode
 const OptionDesc OPTIONS[] = {
   {"bounds_as_shipped", &Options::bounds_as_shipped, 0, 1, true},
   {"traversal", &Options::traversal, 0, 2, true}, {"wavefront", &Options::wavefront, 0, 1, true},
-  {"qnodes", &Options::qnodes, 0, 1, true}, {"shadow_anyhit", &Options::shadow_anyhit, 0, 1, true}, {"skip_unlit", &Options::skip_unlit, 0, 1, true},
+  {"qnodes", &Options::qnodes, 0, 2, true}, {"shadow_anyhit", &Options::shadow_anyhit, 0, 1, true}, {"skip_unlit", &Options::skip_unlit, 0, 1, true},
   {"stack_lds_depth", &Options::stack_lds_depth, -1, 64, false}, {"refill_k", &Options::refill_k, 0, 64, false}, {"batch_k", &Options::batch_k, 1, 64, false},
   {"leaf_k", &Options::leaf_k, 1, 64, false}, {"reps", &Options::reps, 1, 8, false}, {"drain_lanes", &Options::drain_lanes, 0, 64, false},
   {"chunk_shift", &Options::chunk_shift, 0, 12, false}, {"trace_waves", &Options::trace_waves, 0, 1 << 20, false}, {"sched", &Options::sched, 0, 1, false},
@@ -206,15 +206,17 @@ int scene_create(const MirtSceneDesc* d, int device, MirtScene** out)
   {
     const size_t nodes_bytes = N > 1 ? 64 * (size_t)(N - 1) : 0;
     const size_t sph_bytes = 16 * (size_t)sc->Ns, tri_bytes = 48 * (size_t)sc->Nt;
-    // (32-byte quantised node records behind the primitives, scene_dev.h)
-    const size_t qnode_bytes = N > 1 ? 32 * (size_t)(N - 1) : 0;
-    const size_t total = nodes_bytes + sph_bytes + tri_bytes + 64 + qnode_bytes;
+    // (quantised node records behind the primitives, scene_dev.h: 32-byte ones for a sphere-only scene, else the wide ones)
+    const size_t qnode_bytes = (sc->Nt == 0 && N > 1) ? 32 * (size_t)(N - 1) : 0;
+    const size_t wnode_bytes = (sc->Nt > 0 && N > 1) ? 64 * (size_t)(N - 1) + 128 : 0;      // wide records (scene_dev.h), line-aligned
+    const size_t total = nodes_bytes + sph_bytes + tri_bytes + 64 + qnode_bytes + wnode_bytes;
     if (total > 0xfffffff0ull) { delete sc; set_error("mirt_scene_create: scene too large for 32-bit record offsets"); return MIRT_ERR_ARG; }
     hipError_t e = hipMalloc(&sc->heap, total);
     if (e == hipSuccess) e = hipMemset(sc->heap, 0, total);
     if (e != hipSuccess) { delete sc; return hip_fail(e, "hipMalloc(heap)", __FILE__, __LINE__); }
     sc->prim_base = (uint32_t)nodes_bytes;
     sc->qnode_base = qnode_bytes ? (uint32_t)(nodes_bytes + sph_bytes + tri_bytes + 64) : 0u;
+    sc->wnode_base = wnode_bytes ? (uint32_t)((nodes_bytes + sph_bytes + tri_bytes + 64 + qnode_bytes + 127) / 128 * 128) : 0u;
     sc->nodes = reinterpret_cast<float4*>(sc->heap);
   }
   chk(upload(&sc->spheres, spheres)); chk(upload(&sc->tris, tris));

@@ -420,6 +420,47 @@ __global__ void __launch_bounds__(BLOCK) pack_qnodes_kernel(int n, const uint32_
   qnodes[2 * (size_t)p + 1] = make_uint4(w[4], w[5], w[6], w[7]);
 }
 
+// Wide quantised records (scene_dev.h): the grandchildren of every internal node, in the reference's visiting order.
+__global__ void __launch_bounds__(BLOCK) pack_wnodes_kernel(int n, const uint32_t* __restrict__ bkeys, const uint32_t* __restrict__ child_l,
+                                                            const uint32_t* __restrict__ child_r, const float* __restrict__ boxes,
+                                                            const uint32_t* __restrict__ order, const MirtPrimRef* __restrict__ refs,
+                                                            const uint32_t* __restrict__ tris_before, const uint2* __restrict__ range,
+                                                            uint4* __restrict__ wnodes, float* __restrict__ qparams, uint32_t wbase16, uint32_t prim_base16)
+{
+  const int p = blockIdx.x * BLOCK + threadIdx.x;
+  if (p >= n - 1) return;
+  float smin[3], step[3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    smin[k] = key2f(bkeys[k]);
+    const float range = key2f(bkeys[3 + k]) - smin[k];
+    step[k] = range > 0.0f ? range / QGRID : 1.0f;
+  }
+  if (p == 0) { for (int k = 0; k < 3; ++k) { qparams[k] = smin[k]; qparams[3 + k] = step[k]; qparams[6 + k] = QINV_STEPS / step[k]; } }
+  const uint32_t leaf_base = (uint32_t)(n - 1);
+  uint32_t kids[4];
+  int nk = 0;
+  const uint32_t two[2] = {child_l[p], child_r[p]};
+  for (int s = 0; s < 2; ++s) {
+    if (two[s] >= leaf_base) kids[nk++] = two[s];
+    else { kids[nk++] = child_l[two[s]]; kids[nk++] = child_r[two[s]]; }
+  }
+  uint32_t w[16];
+  for (int i = 0; i < 4; ++i) {
+    if (i < nk) {
+      const float* b = boxes + 6 * (size_t)kids[i];
+      for (int k = 0; k < 3; ++k) w[3 * i + k] = qlo(b[2 * k], smin[k], step[k]) | (qhi(b[2 * k + 1], smin[k], step[k]) << 16);
+      bool pure;
+      const uint32_t r = make_ref(kids[i], leaf_base, order, refs, tris_before, range, prim_base16, &pure);
+      w[12 + i] = kids[i] >= leaf_base ? r : (wbase16 + 4u * kids[i]);
+    } else {
+      w[3 * i + 0] = QBOX_NONE; w[3 * i + 1] = QBOX_NONE; w[3 * i + 2] = QBOX_NONE;
+      w[12 + i] = REF_NONE;
+    }
+  }
+  for (int i = 0; i < 4; ++i) wnodes[4 * (size_t)p + i] = make_uint4(w[4 * i + 0], w[4 * i + 1], w[4 * i + 2], w[4 * i + 3]);
+}
+
 // primitive records in sorted order + the unit -> primitive map the shading code uses to find the material
 __global__ void __launch_bounds__(BLOCK) scatter_prims_kernel(int n, const uint32_t* __restrict__ order, const MirtPrimRef* __restrict__ refs,
                                                               const uint32_t* __restrict__ tris_before, const float4* __restrict__ spheres,
@@ -576,6 +617,14 @@ int build_lbvh(MirtScene* sc, hipStream_t stream)
     hipLaunchKernelGGL(pack_qnodes_kernel, dim3(kblk), dim3(BLOCK), 0, stream, n, sc->bounds_keys, sc->child_l, sc->child_r, sc->boxes,
                        sc->order, sc->refs_in, sc->tris_before, sc->range, reinterpret_cast<uint4*>(sc->heap + sc->qnode_base), sc->qparams, sc->qnode_base / 16u, sc->prim_base / 16u);
     sc->root_ref_q = sc->qnode_base / 16u;
+  }
+  sc->root_ref_w = REF_NONE;
+  if (sc->wnode_base && n > 1 && !sc->opt.bounds_as_shipped) {
+    const int kblk = (n - 1 + BLOCK - 1) / BLOCK;
+    hipLaunchKernelGGL(pack_wnodes_kernel, dim3(kblk), dim3(BLOCK), 0, stream, n, sc->bounds_keys, sc->child_l, sc->child_r, sc->boxes,
+                       sc->order, sc->refs_in, sc->tris_before, sc->range, reinterpret_cast<uint4*>(sc->heap + sc->wnode_base),
+                       sc->qparams, sc->wnode_base / 16u, sc->prim_base / 16u);
+    sc->root_ref_w = sc->wnode_base / 16u;
   }
   MIRT_HIP(hipGetLastError());
   MIRT_HIP(hipEventRecord(sc->ev1, stream));

@@ -73,11 +73,14 @@ MIRT_DEV bool triangle_leaf_reached(const RenderArgs* __restrict__ ap, uint32_t 
 // QN: the walk starts on the 32-byte quantised node records (scene_dev.h); SPECX: SPEC_NOTRI / SPEC_NOBULB / SPEC_NOPEND of
 // shade_common.h.  With QN and triangles a lane can also be on the 64-byte exact records (S.qsx == 0: its ray is being walked
 // again, triangle_leaf_reached); then S.inv holds 1 / d.
+// With QN on a scene that has triangles the quantised records are the wide ones (WIDE, scene_dev.h): a step tests the boxes of
+// the node's four grandchildren and descends two levels.
 template <bool COUNT, int TABLES, bool QN, int SPECX = 0>
 __global__ void __launch_bounds__(TRACE_BLOCK, MIRT_WAVES_PER_SIMD) trace_kernel(const RenderArgs* __restrict__ ap, const HotArgs h)
 {
   constexpr int SPEC = SPECX;
   constexpr bool NOTRI = (SPEC & SPEC_NOTRI) != 0;
+  constexpr bool WIDE = QN && !NOTRI;
   __shared__ __attribute__((aligned(16))) unsigned char lds_raw[STACK_LDS * TRACE_BLOCK * 4];     // traversal stacks: STACK_LDS x TRACE_BLOCK words
   // The random-number state (8 words per lane) is only touched in the shade phase: it lives here during traversal so
   // that it does not occupy registers across the hot loop (the kernel runs at the 128-VGPR edge of 4 waves per SIMD).
@@ -102,9 +105,6 @@ __global__ void __launch_bounds__(TRACE_BLOCK, MIRT_WAVES_PER_SIMD) trace_kernel
   unsigned long long c_next = 0, c_end = 0;   // wave-uniform: this wave's current chunk
   bool exhausted = false;                      // wave-uniform: the global counter has run past the frame
 
-#if MIRT_PF_PUSH
-  uint32_t pfv = 0;
-#endif
   Lane S;
   S.g = -1; S.trav = false;
   S.rng.v0 = S.rng.v1 = S.rng.v2 = S.rng.v3 = S.rng.v4 = S.rng.d = 0; S.rng.bm_flag = 0; S.rng.bm_extra = 0.0f;
@@ -264,13 +264,39 @@ __global__ void __launch_bounds__(TRACE_BLOCK, MIRT_WAVES_PER_SIMD) trace_kernel
           bool hl, hr;
           float tel, ter;
           uint32_t lref, rref;
-          if (QN && (NOTRI || S.qsx != 0u)) {
-            // two 16-byte requests: twelve grid coordinates and the child references (REF_QPURE on the first one: both subtrees
-            // hold spheres only -- every node of a sphere-only scene)
+          // push `v`: the previous top of stack goes to memory, the new top stays in a register.  With n entries on the stack,
+          // entry k < n sits in slot k and entry n is S.tos (slot 0 only ever receives the dead S.tos of an empty stack), so
+          // the slot to write is simply the current depth.
+#define MIRT_PUSH(v) do { if (S.sp < h.lds_depth) lds_stack[S.sp * TRACE_BLOCK + tid] = S.tos; \
+                          else h.stack_spill[(size_t)(S.sp - h.lds_depth) * gthreads + gid] = S.tos; \
+                          S.tos = (v); ++S.sp; if (COUNT) cn.max_stack = max(cn.max_stack, (uint32_t)S.sp); } while (0)
+          if (WIDE && S.qsx != 0u) {
+            // four 16-byte requests: the boxes of up to four grandchildren in the reference's visiting order, their references.
+            // The first one hit is descended, the others are pushed last first -- the reference's depth-first order over a
+            // superset of the nodes it visits (it tests the children of the right child only when that is popped, against a
+            // best distance that may have shrunk meanwhile).  The last push is the common one below.
+            const uint4 w0 = *reinterpret_cast<const uint4*>(nrec), w1 = *reinterpret_cast<const uint4*>(nrec + 1);
+            const uint4 w2 = *reinterpret_cast<const uint4*>(nrec + 2), w3 = *reinterpret_cast<const uint4*>(nrec + 3);
+            const bool h0 = box_q(w0.x, w0.y, w0.z, S.inv, S.qb, S.qc, S.qsx, S.qsy, S.qsz, S.tbest, tmin);
+            const bool h1 = box_q(w0.w, w1.x, w1.y, S.inv, S.qb, S.qc, S.qsx, S.qsy, S.qsz, S.tbest, tmin);
+            const bool h2 = box_q(w1.z, w1.w, w2.x, S.inv, S.qb, S.qc, S.qsx, S.qsy, S.qsz, S.tbest, tmin);
+            const bool h3 = box_q(w2.y, w2.z, w2.w, S.inv, S.qb, S.qc, S.qsx, S.qsy, S.qsz, S.tbest, tmin);
+            uint32_t cand = w3.w;
+            bool have = h3;
+            if (h2 && have) MIRT_PUSH(cand);
+            cand = h2 ? w3.z : cand; have = have || h2;
+            if (h1 && have) MIRT_PUSH(cand);
+            cand = h1 ? w3.y : cand; have = have || h1;
+            hl = h0 || have; hr = h0 && have;
+            lref = h0 ? w3.x : cand; rref = cand;
+            tel = 0.0f; ter = 0.0f;
+          } else if (QN && NOTRI) {
+            // two 16-byte requests: twelve grid coordinates and the child references; every node of a sphere-only scene may be
+            // descended near child first
             const uint4 w0 = *reinterpret_cast<const uint4*>(nrec), w1 = *reinterpret_cast<const uint4*>(nrec + 1);
             box_pair_q(w0, w1.x, w1.y, S.inv, S.qb, S.qc, S.qsx, S.qsy, S.qsz, S.tbest, tmin, hl, hr, tel, ter);
             lref = w1.z; rref = w1.w;
-            order_children(hl, hr, tel, ter, NOTRI ? (NODE_SWAP_ANY | NODE_SWAP_PURE) : (NODE_SWAP_ANY | ((w1.z >> 29) & 1u)), h.swap_mask, lref, rref);
+            order_children(hl, hr, tel, ter, NODE_SWAP_ANY | NODE_SWAP_PURE, h.swap_mask, lref, rref);
           } else {
             const float4 q0 = nrec[0], q1 = nrec[1], q2 = nrec[2];
             const uint4 ch = *reinterpret_cast<const uint4*>(nrec + 3);      // child references, NODE_SWAP_* flags
@@ -278,9 +304,6 @@ __global__ void __launch_bounds__(TRACE_BLOCK, MIRT_WAVES_PER_SIMD) trace_kernel
             lref = ch.x; rref = ch.y;
             order_children(hl, hr, tel, ter, ch.z, h.swap_mask, lref, rref);
           }
-#if MIRT_PF_PUSH
-          asm volatile("" :: "v"(pfv));
-#endif
           // first child next, push the second (bvh_traversal.cu:149-157: left, right), written with selects: one short
           // branch for the push
           const bool both = hl && hr;
@@ -288,19 +311,8 @@ __global__ void __launch_bounds__(TRACE_BLOCK, MIRT_WAVES_PER_SIMD) trace_kernel
           // lbvh_builder.cu:76-101 is a radix tree over (code, index) keys of 30 + ceil(log2 N) bits, N < 2^28 (checked at scene
           // creation), so it is at most 58 levels deep, and the walk keeps at most one pending sibling per level.  The
           // reference's "stack overflow" warning, bvh_traversal.cu:154-164, is unreachable for the same reason.)
-          if (both) {
-            // the previous top of stack goes to memory, the new top stays in a register.  With n entries on the stack,
-            // entry k < n sits in slot k and entry n is S.tos (slot 0 only ever receives the dead S.tos of an empty
-            // stack), so the slot to write is simply the current depth.
-            if (S.sp < h.lds_depth) lds_stack[S.sp * TRACE_BLOCK + tid] = S.tos;
-            else h.stack_spill[(size_t)(S.sp - h.lds_depth) * gthreads + gid] = S.tos;
-            S.tos = rref;
-            ++S.sp;
-#if MIRT_PF_PUSH
-            pfv = *reinterpret_cast<const uint32_t*>(heap + (rref << 4));      // experiment: touch the pushed sibling's record
-#endif
-            if (COUNT) cn.max_stack = max(cn.max_stack, (uint32_t)S.sp);
-          }
+          if (both) MIRT_PUSH(rref);
+#undef MIRT_PUSH
           S.cur = hl ? lref : (hr ? rref : S.cur);
           pop = !(hl || hr);
         }
@@ -648,7 +660,7 @@ static int render_impl(MirtScene* sc, const MirtRenderParams* p, void* d_rgba8, 
     MIRT_HIP(hipMalloc(&cx.samples, sizeof(float4) * (size_t)slab_samples_max));
     cx.samples_cap = (size_t)slab_samples_max;
   }
-  const size_t spill_need = (size_t)STACK_TOTAL * gthreads;
+  const size_t spill_need = (size_t)STACK_TOTAL_WIDE * gthreads;      // (the wide walk pushes up to three entries per two levels)
   if (cx.spill_cap < spill_need) {
     MIRT_HIP(hipStreamSynchronize(stream));
     hipFree(cx.stack_spill); cx.stack_spill = nullptr; cx.spill_cap = 0;
@@ -678,12 +690,17 @@ static int render_impl(MirtScene* sc, const MirtRenderParams* p, void* d_rgba8, 
   a.stripe_rows = p->stripe_rows; a.num_parts = p->num_parts; a.part = p->part;
   a.sample_first = sample_first; a.sample_count = sample_count; a.seed_per_pixel = per_pixel_seed ? 1 : 0;
   a.nodes = sc->nodes; a.unit_prim = sc->unit_prim; a.mats = sc->mats;
-  // quantised node records: single-kernel path, any order but the reference's own
-  const bool qn = sc->root_ref_q != REF_NONE && opt.qnodes != 0 && opt.traversal >= 1 && opt.wavefront == 0;
+  // Quantised node records: single-kernel path, any order but the reference's own.  A sphere-only scene: the 32-byte records,
+  // always.  A scene with triangles: the wide records -- the reference's order at every node, so traversal = 1 only -- when the
+  // scene is large enough for memory to matter (qnodes = 1: N >= 65536, the exact records no longer fit an L2; redchair.txt's
+  // 1.7 k primitives are 12 % faster on the exact records, the 2 M-primitive scene 25 % faster on the wide ones) or always (2).
   const bool notri = sc->Nt == 0;
+  const bool qwant = opt.qnodes != 0 && opt.wavefront == 0;
+  const bool qn = notri ? (qwant && opt.traversal >= 1 && sc->root_ref_q != REF_NONE)
+                        : (qwant && opt.traversal == 1 && sc->root_ref_w != REF_NONE && (opt.qnodes >= 2 || sc->N >= 65536));
   // kernels specialised for what the scene does not have (SPEC_*, shade_common.h)
   const bool nobulb = opt.specialise != 0 && sc->d.num_bulbs == 0, nopend = opt.specialise != 0 && !need_pending;
-  a.root_ref = qn ? sc->root_ref_q : sc->root_ref; a.num_spheres = sc->Ns; a.num_prims = sc->N;
+  a.root_ref = qn ? (notri ? sc->root_ref_q : sc->root_ref_w) : sc->root_ref; a.num_spheres = sc->Ns; a.num_prims = sc->N;
   a.qparams = qn ? sc->qparams : nullptr;
   a.tri_boxes = sc->tri_boxes;
   a.prim_base16 = sc->prim_base / 16u;
@@ -705,7 +722,7 @@ static int render_impl(MirtScene* sc, const MirtRenderParams* p, void* d_rgba8, 
   a.counters = count ? cx.counters : nullptr;
   a.overflow = cx.counters + 9;
   a.lds_depth = (opt.stack_lds_depth >= 0 && opt.stack_lds_depth <= STACK_LDS) ? opt.stack_lds_depth : STACK_LDS;   // tests force the spill path
-  a.refill_k = opt.refill_k > 0 ? opt.refill_k : (qn ? 32 : 44);
+  a.refill_k = opt.refill_k > 0 ? opt.refill_k : (qn ? (notri ? 32 : 28) : 44);      // (measured: sphere-only 32, wide records on the 2 M-primitive scene 24-28, exact records 44)
   a.drain_lanes = opt.drain_lanes;
   a.batch_k = opt.batch_k;
 

@@ -34,6 +34,14 @@ constexpr uint32_t REF_NONE = 0xf0000000u;   // no record (bits 29..28 are set i
 // Node i sits at heap offset qnode_base + 32 i: its reference is qnode_base / 16 + 2 i.
 constexpr float QGRID = 65535.0f;
 constexpr uint32_t REF_QPURE = 0x20000000u;
+// Wide quantised records (scenes with triangles, option "wide"): one 64-byte record per internal node P holding the boxes of P's
+// GRANDchildren (a child of P that is a leaf stands for itself) in the reference's visiting order -- up to four boxes of
+// 3 words each (words 0..11; an absent slot holds an inverted box, which no ray hits) -- and their four references (words
+// 12..15).  A step tests four boxes and descends two levels: half as many dependent memory round trips per ray.  The walk
+// visits a superset of the reference's leaves in the reference's order (render.hip), which is all that exactness needs.
+// Node i sits at heap offset wnode_base + 64 i.
+constexpr uint32_t QBOX_NONE = 0x0000ffffu;   // lo = 65535, hi = 0
+constexpr int STACK_TOTAL_WIDE = 88;          // up to three pushes per two levels of a tree at most 58 levels deep
 constexpr float QINV_STEPS = 1152921504606846976.0f;   // 2^60: |1 / d| is clamped to this many grid steps per unit of t (quantised_axis)
 // node record word 14 (after the two child references): which descent orders the node allows
 constexpr uint32_t NODE_SWAP_PURE = 1u;       // both subtrees hold spheres only: near-child-first cannot change the closest hit
@@ -148,7 +156,8 @@ struct Options {
   int trace_waves = 0;         // 0: fill the device
   int shadow_anyhit = 1;       // 0: shadow rays are nearest-hit queries, as in diffuseLight (draw.cu:347-352, 365-370): the reference's walk, more node visits
   int skip_unlit = 1;          // 0: shadow rays towards lights the shading normal faces away from are traced as well (draw.cu:342-374 traces them all)
-  int qnodes = 1;              // sphere-only scenes: 32-byte quantised node records in the single-kernel path (traversal >= 1)
+  int qnodes = 1;              // quantised node records in the single-kernel path: 0 never; 1 sphere-only scenes (traversal >= 1) and scenes with
+                               // triangles of 65536 primitives or more (wide records, traversal = 1); 2 every scene
   int specialise = 1;          // kernels compiled without what the scene does not have: point lights; transparency and gi (SPEC_*, shade_common.h)
   int sched = 1;               // longest-first chunk order measured on earlier frames
   int slab_log2 = 26;          // a call is rendered in slabs of at most 2^slab_log2 samples (1 GiB of per-sample workspace)
@@ -212,6 +221,8 @@ struct MirtScene {
   uint32_t* tris_before = nullptr;      // [N + 1]: triangles among sorted leaves [0, j)
   uint2* range = nullptr;               // [N - 1]: sorted-leaf range (first, last) of every internal node
   uint32_t qnode_base = 0;              // byte offset of the quantised node records in the heap (0: none built)
+  uint32_t wnode_base = 0;              // byte offset of the wide quantised records (scenes with triangles; 0: none built)
+  uint32_t root_ref_w = mirt::REF_NONE; // root reference into the wide records
   uint32_t root_ref_q = mirt::REF_NONE; // root reference into the quantised records
   float* qparams = nullptr;             // [9] device: grid origin, grid step, 2^60 / grid step
   float4* tri_boxes = nullptr;          // [2 Nt]: exact leaf box of every triangle (scene order), for the quantised walk's triangle check

@@ -164,6 +164,19 @@ MIRT_DEV void box_pair_q(const uint4 w0, const uint32_t w4, const uint32_t w5, c
   ter = te;
 }
 
+// one box of a wide record (scene_dev.h): the same arithmetic as box_pair_q on three words
+MIRT_DEV bool box_q(const uint32_t wx, const uint32_t wy, const uint32_t wz, const f3& A, const f3& Cn, const f3& Cf, uint32_t sx, uint32_t sy, uint32_t sz,
+                    float tbest, float tmin)
+{
+  const uint32_t magic = 0x4b000000u;
+  const float nx = __builtin_fmaf(__uint_as_float(__builtin_amdgcn_perm(magic, wx, sx)), A.x, Cn.x), fx = __builtin_fmaf(__uint_as_float(__builtin_amdgcn_perm(magic, wx, sx ^ 0x0202u)), A.x, Cf.x);
+  const float ny = __builtin_fmaf(__uint_as_float(__builtin_amdgcn_perm(magic, wy, sy)), A.y, Cn.y), fy = __builtin_fmaf(__uint_as_float(__builtin_amdgcn_perm(magic, wy, sy ^ 0x0202u)), A.y, Cf.y);
+  const float nz = __builtin_fmaf(__uint_as_float(__builtin_amdgcn_perm(magic, wz, sz)), A.z, Cn.z), fz = __builtin_fmaf(__uint_as_float(__builtin_amdgcn_perm(magic, wz, sz ^ 0x0202u)), A.z, Cf.z);
+  const float te = fmaxf(fmaxf(nx, ny), nz);
+  const float tx = fminf(fminf(fx, fy), fz);
+  return te < tx && te < tbest && tx > tmin;
+}
+
 // One axis of a ray in the grid of the quantised node records (start_ray): A, the offsets of the near and the far plane for
 // f = 2^23 + q, and the permute selector of the near plane's half-word.  C0 = B - 2^23 A is the offset of the plain form
 // q * A + B; the margin E = 2^-20 |B| + 1.0625 |A| exceeds every rounding on the way: of A, of B and of the final fused

@@ -109,6 +109,14 @@ typedef struct {
  * t <= t_max then), so the reference's walk reaches this leaf and finds the same hit.  Otherwise the ray is walked AGAIN from
  * the root over the exact boxes (same order flags): rare (triangle silhouettes), exact. */
 #define ORC_FLAG_QNODES        32u
+/* Wide walk over the quantised records (the product's records for scenes with triangles, scene_dev.h): a step at internal node P
+ * tests the boxes of P's GRANDchildren (a child that is a leaf stands for itself) -- up to four, in the reference's order
+ * (left subtree first) -- and descends into the first one hit, pushing the others.  The reference tests the children of R only
+ * when R is popped, i.e. against a best distance that may have shrunk meanwhile, and it tests L and R themselves; this walk
+ * tests them early and skips L and R (their boxes contain their children's): it visits a superset of the reference's leaves in
+ * the same order, which is all the argument under ORC_FLAG_QNODES needs.  Half as many dependent steps per ray.  Needs QNODES;
+ * the descent order is the reference's at every node (no near-child-first, not even between sphere-only subtrees). */
+#define ORC_FLAG_WIDE          64u
 #define ORC_FLAG_ORDERED       4u
 #define ORC_FLAG_ORDERED_ALL   8u   /* near child first at every node (triangle silhouettes may differ from the reference order) */
 
@@ -803,8 +811,81 @@ static Obj traverse_ordered(Ctx& cx, const Ray& ray, float initial_t_max, bool e
   return best;
 }
 
+/* ORC_FLAG_WIDE (above): the leaf handling is traverse_ordered's with quantised boxes. */
+static Obj traverse_wide(Ctx& cx, const Ray& ray, float initial_t_max, bool early, float stop_below)
+{
+  const Scene& sc = *cx.sc;
+  Obj best = obj_none();
+  best.distance = initial_t_max;
+  float tmax = initial_t_max;
+  bool have = false;
+  uint32_t best_leaf = 0;
+  V3 inv = mk(1.0f / ray.dir.x, 1.0f / ray.dir.y, 1.0f / ray.dir.z);
+  const float tmin = 0.0001f;
+  uint32_t stack[192];
+  int sp = 0;
+  uint32_t cur = 0;
+  float qstep[3];
+  for (int k = 0; k < 3; ++k) { float range = sc.smax[k] - sc.smin[k]; qstep[k] = range > 0.0f ? range / 65535.0f : 1.0f; }
+  const QAxis qax[3] = {quantised_axis(sc.smin[0], qstep[0], ray.eye.x, inv.x), quantised_axis(sc.smin[1], qstep[1], ray.eye.y, inv.y),
+                        quantised_axis(sc.smin[2], qstep[2], ray.eye.z, inv.z)};
+  while (true) {
+    const ONode& node = sc.nodes[cur];
+    cx.st.node_iters++;
+    if (node.count > 0) {
+      const uint32_t k = node.prim_offset;
+      const OPrimRef& ref = sc.refs[k];
+      Obj h;
+      if (ref.type == 0) {
+        h = check_sphere(cx, ray, ref.id); cx.st.sphere_tests++;
+        if (h.isHit) {      /* the two order-independent clauses of the exact leaf box test */
+          float te;
+          if (!hit_aabb_t(node, ray.eye, inv, tmin, INFINITY, &te)) h.isHit = false;
+        }
+      }
+      else { h = check_triangle(cx, ray, ref.id); cx.st.tri_tests++; }
+      if (h.isHit && h.distance > 1e-6f && (h.distance < tmax || (have && h.distance == tmax && k < best_leaf))) {
+        if (ref.type != 0) {
+          float te;
+          const bool box_ok = hit_aabb_t(node, ray.eye, inv, tmin, INFINITY, &te);
+          if (!(box_ok && te < h.distance)) { cx.st.qn_retraces++; return traverse_ordered(cx, ray, initial_t_max, early, stop_below, false); }
+        }
+        tmax = h.distance; best = h; best_leaf = k; have = true;
+        if (early && best.distance < stop_below) return best;
+      }
+      if (sp == 0) break;
+      cur = stack[--sp];
+      continue;
+    }
+    cx.st.internal_visits++;
+    uint32_t kids[4];
+    int nk = 0;
+    const uint32_t two[2] = {node.left, node.right};
+    for (int s = 0; s < 2; ++s) {
+      const ONode& c = sc.nodes[two[s]];
+      if (c.count > 0) kids[nk++] = two[s];
+      else { kids[nk++] = c.left; kids[nk++] = c.right; }
+    }
+    uint32_t hit[4];
+    int nh = 0;
+    for (int i = 0; i < nk; ++i) { float te; if (hit_qbox(sc.nodes[kids[i]], sc.smin, qstep, qax, tmin, tmax, &te)) hit[nh++] = kids[i]; }
+    if (nh == 0) {
+      if (sp == 0) break;
+      cur = stack[--sp];
+      continue;
+    }
+    cur = hit[0];
+    for (int i = nh - 1; i >= 1; --i) {
+      if (sp < 192) { stack[sp++] = hit[i]; if ((uint64_t)sp > cx.st.max_stack) cx.st.max_stack = (uint64_t)sp; }
+      else cx.st.overflow++;
+    }
+  }
+  return best;
+}
+
 static inline Obj traverse_any(Ctx& cx, const Ray& ray, float initial_t_max, bool early, float stop_below)
 {
+  if ((cx.flags & ORC_FLAG_WIDE) && (cx.flags & ORC_FLAG_QNODES) && cx.sc->refs.size() > 1) return traverse_wide(cx, ray, initial_t_max, early, stop_below);
   if (cx.flags & (ORC_FLAG_ORDERED | ORC_FLAG_ORDERED_ALL)) return traverse_ordered(cx, ray, initial_t_max, early, stop_below);
   return traverse(cx, ray, initial_t_max, early, stop_below);
 }

@@ -16,20 +16,27 @@ FLAG_SKIP_UNLIT = 16    # shadow rays towards lights the shading normal faces aw
 # what libmirt does: any-hit shadow rays and no shadow rays to unlit lights, always; ordered traversal
 # where pixels cannot change, by default -- the oracle mirrors each so that the visit counters can be compared with ==
 FLAG_QNODES = 32        # quantised node records (single-kernel path, traversal >= 1; triangle hits outside their exact leaf box re-walk the exact boxes)
+FLAG_WIDE = 64          # wide walk over the quantised records: grandchildren tested per step, reference order (scenes with triangles)
 PRODUCT_ALWAYS = FLAG_ANYHIT_SHADOW | FLAG_SKIP_UNLIT      # (the defaults of the scene options shadow_anyhit / skip_unlit)
-PRODUCT_FLAGS = PRODUCT_ALWAYS | FLAG_ORDERED | FLAG_QNODES   # default options, single-kernel path, more than one primitive
+PRODUCT_FLAGS = PRODUCT_ALWAYS | FLAG_ORDERED | FLAG_QNODES   # default options, single-kernel path, a scene WITHOUT triangles
+PRODUCT_FLAGS_TRI = PRODUCT_FLAGS | FLAG_WIDE                 # ... a scene with triangles and 65536 primitives or more (or qnodes = 2)
+PRODUCT_FLAGS_SMALL_TRI = PRODUCT_ALWAYS | FLAG_ORDERED       # ... a smaller scene with triangles: the exact records
 REFERENCE_WALK = 0      # {traversal: 0, shadow_anyhit: 0, skip_unlit: 0, qnodes: 0}: draw.cu:292-377 + bvh_traversal.cu:92-183 verbatim
 
 
-def product_flags(scene_has_triangles=False, traversal=1, wavefront=False, qnodes=True, shadow_anyhit=True, skip_unlit=True):
-    """The oracle flags that mirror what libmirt does for an option set (for counters to compare with ==)."""
+def product_flags(scene_has_triangles, traversal=1, wavefront=False, qnodes=1, shadow_anyhit=True, skip_unlit=True, nprims=0):
+    """The oracle flags that mirror what libmirt does for an option set (for counters to compare with ==).  qnodes: the scene
+    option (0 never, 1 sphere-only scenes and scenes with triangles of 65536 primitives or more, 2 every scene)."""
     f = {0: 0, 1: FLAG_ORDERED, 2: FLAG_ORDERED_ALL}[traversal]
     if shadow_anyhit:
         f |= FLAG_ANYHIT_SHADOW
     if skip_unlit:
         f |= FLAG_SKIP_UNLIT
-    if qnodes and traversal >= 1 and not wavefront:
-        f |= FLAG_QNODES
+    if qnodes and not wavefront:
+        if not scene_has_triangles and traversal >= 1:
+            f |= FLAG_QNODES
+        elif scene_has_triangles and traversal == 1 and (qnodes >= 2 or nprims >= 65536):
+            f |= FLAG_QNODES | FLAG_WIDE
     return f
 
 

@@ -13,7 +13,7 @@ sys.path.insert(0, os.path.join(ROOT, "tools"))
 import pytest
 
 
-@pytest.mark.parametrize("kernel", ["trace_kernelILb0ELi8ELb1ELi7EE", "trace_kernelILb0ELi8ELb1ELi1EE", "trace_kernelILb0ELi8ELb1ELi6EE", "trace_kernelILb0ELi8ELb1ELi2EE", "trace_kernelILb0ELi8ELb1ELi0EE", "trace_kernelILb0ELi8ELb0ELi6EE",
+@pytest.mark.parametrize("kernel", ["trace_kernelILb0ELi8ELb1ELi7EE", "trace_kernelILb0ELi8ELb1ELi1EE", "trace_kernelILb0ELi8ELb1ELi6EE", "trace_kernelILb0ELi8ELb0ELi6EE",
                                     "trace_kernelILb0ELi8ELb0ELi2EE", "trace_kernelILb0ELi8ELb0ELi0EE"])
 def test_no_scratch_reloads_on_the_traversal_loop_hot_path(kernel):
     """Both node formats of the 16-spp kernel -- quantised records (sphere-only scenes: the headline) and 64-byte records -- in

@@ -28,7 +28,7 @@ def run_case(text, w, h, spp, **options):
     tree = raw.tree() if stl.num_prims > 0 else None
     raw.close()
     o = ol.OracleScene(pyscene.parse_lines(text.split("\n")), bounds_mode=0)
-    ref = o.render(w, h, spp, flags=ol.product_flags(stl.num_triangles > 0, qnodes=options.get("qnodes", 1) != 0), nthreads=8)
+    ref = o.render(w, h, spp, flags=ol.product_flags(stl.num_triangles > 0, qnodes=options.get("qnodes", 1), nprims=stl.num_prims), nthreads=8)
     if tree is not None:
         on = o.nodes()
         for f in ("left", "right"):
@@ -46,9 +46,11 @@ def run_case(text, w, h, spp, **options):
 
 
 @pytest.mark.parametrize("name", [n for n in edge_scenes.ALL if n != "deep_stack"])
-@pytest.mark.parametrize("spp", [0, 1, 8])
-def test_edge_scene_matches_oracle(name, spp):
-    st, img = run_case(edge_scenes.ALL[name](), 64, 48, spp)
+@pytest.mark.parametrize("spp,qnodes", [(0, 1), (1, 1), (8, 1), (8, 2)])
+def test_edge_scene_matches_oracle(name, spp, qnodes):
+    """(qnodes = 2: quantised records on every scene -- the wide walk on the scenes with triangles, which are far too small to get
+    it by default.)"""
+    st, img = run_case(edge_scenes.ALL[name](), 64, 48, spp, qnodes=qnodes)
     if name == "empty":
         assert img.max() == 0
     if name in ("plane_only", "single_sphere", "bulbs_and_planes"):
@@ -81,11 +83,12 @@ def test_general_kernels_on_scenes_that_have_specialised_ones(name):
     run_case(edge_scenes.ALL[name](), 64, 48, 4, specialise=0)
 
 
-@pytest.mark.parametrize("seed,triangles", [(31, 0.0), (32, 0.0), (33, 1.0)])
-def test_random_scenes_match_the_oracle_with_equal_counters(seed, triangles):
+@pytest.mark.parametrize("seed,triangles,qnodes", [(31, 0.0, 1), (32, 0.0, 1), (33, 1.0, 1), (33, 1.0, 2), (34, 3.0, 2)])
+def test_random_scenes_match_the_oracle_with_equal_counters(seed, triangles, qnodes):
     """25 random scenes per seed from tools/fuzz_modes.py's generator (scales 1e-3 .. 1e6, cameras inside / outside / far away,
-    fisheye / panorama, depth of field, some with point lights, glass and gi; seed 33: with triangles): colours within 1e-4 of
-    the oracle's, 8-bit image within one level, the tree's child links and every ray / node / leaf counter equal."""
+    fisheye / panorama, depth of field, some with point lights, glass and gi; seeds 33, 34: with triangles -- on the exact records,
+    and with qnodes = 2 over the wide quantised ones): colours within 1e-4 of the oracle's, 8-bit image within one level, the
+    tree's child links and every ray / node / leaf counter equal."""
     import os
     import sys
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
@@ -95,7 +98,7 @@ def test_random_scenes_match_the_oracle_with_equal_counters(seed, triangles):
         text = fuzz_modes.scene_text(rng, triangles)
         spp = int(rng.choice([0, 1, 3]))
         try:
-            run_case(text, 48, 32, spp)
+            run_case(text, 48, 32, spp, qnodes=qnodes)
         except AssertionError as e:
             raise AssertionError(f"scene {i} of seed {seed} (spp {spp}): {e}") from e
 

@@ -154,7 +154,7 @@ def test_config4_redchair_4k_64spp_stripes_match_oracle(gpu_scenes, oracle_scene
     part = 333
     gu8, gf = gpu_render(raw, w, h, spp, stripe_rows=rows, num_parts=parts, part=part)
     o = oracle_scenes("redchair")
-    refs = [o.render(w, h, spp, tile=(0, (part + j * parts) * rows, w, rows), flags=ol.PRODUCT_FLAGS, nthreads=8) for j in range(2)]
+    refs = [o.render(w, h, spp, tile=(0, (part + j * parts) * rows, w, rows), flags=ol.PRODUCT_FLAGS_SMALL_TRI, nthreads=8) for j in range(2)]
     ref = dict(f32=np.concatenate([r["f32"].reshape(-1, 4) for r in refs]), u8=np.concatenate([r["u8"].reshape(-1, 4) for r in refs]))
     check_image(gu8, gf, ref)
 
@@ -170,10 +170,19 @@ def test_config5_two_million_primitives_4k_256spp_stripe_matches_oracle():
     gu8, gf = gpu_render(raw, w, h, spp, stripe_rows=rows, num_parts=parts, part=part, counters=True)
     st = raw.stats()
     o = ol.OracleScene(ol.ArrayScene(stl), bounds_mode=0)
-    ref = o.render(w, h, spp, tile=(0, part, w, rows), flags=ol.PRODUCT_FLAGS, nthreads=8)
+    ref = o.render(w, h, spp, tile=(0, part, w, rows), flags=ol.PRODUCT_FLAGS_TRI, nthreads=8)
     check_image(gu8, gf, ref)
     for k in ("samples", "rays", "shadow_rays", "internal_visits", "sphere_tests", "tri_tests", "mat_fetches", "max_stack"):
         assert st[k] == ref["stats"][k], (k, st[k], ref["stats"][k])
+    # the same row walked over the exact records (qnodes = 0): identical bytes, its own counters
+    for opts, flags in ((dict(qnodes=0), ol.product_flags(True, qnodes=0)),):
+        with options(raw, **opts):
+            b8, bf = gpu_render(raw, w, h, spp, stripe_rows=rows, num_parts=parts, part=part, counters=True)
+            sb = raw.stats()
+        assert np.array_equal(gu8, b8) and np.array_equal(gf.view(np.uint32), bf.view(np.uint32))
+        refb = o.render(w, h, spp, tile=(0, part, w, rows), flags=flags, nthreads=8)
+        for k in COUNTER_KEYS:
+            assert sb[k] == refb["stats"][k], (opts, k, sb[k], refb["stats"][k])
     raw.close()
     o.close()
 
@@ -198,7 +207,7 @@ def test_config5_ordered_everywhere_gives_the_same_bytes_on_this_scene():
     assert np.array_equal(a8, b8) and np.array_equal(af.view(np.uint32), bf.view(np.uint32))
     assert sa["rays"] == sb["rays"] and sb["internal_visits"] < 0.5 * sa["internal_visits"]
     o = ol.OracleScene(ol.ArrayScene(stl), bounds_mode=0)
-    ref = o.render(w, h, spp, tile=(0, part, w, rows), flags=ol.product_flags(traversal=2), nthreads=8)
+    ref = o.render(w, h, spp, tile=(0, part, w, rows), flags=ol.product_flags(True, traversal=2), nthreads=8)
     n = w * rows
     check_image(b8[:n], bf[:n], ref)
     rawc = m.initRawConfigFromStl(stl, 0)          # counters of the first row alone, against the oracle
@@ -247,7 +256,7 @@ def test_synthetic_scene_build_and_render_match_oracle(ns, nt):
     w, h, spp = 96, 54, 4
     gu8, gf = gpu_render(raw, w, h, spp, counters=True)
     st = raw.stats()
-    ref = o.render(w, h, spp, flags=ol.PRODUCT_FLAGS, nthreads=8)
+    ref = o.render(w, h, spp, flags=ol.product_flags(True, nprims=ns + nt), nthreads=8)
     check_image(gu8, gf, ref)
     for k in ("rays", "internal_visits", "sphere_tests", "tri_tests", "max_stack"):
         assert st[k] == ref["stats"][k], k
@@ -277,15 +286,17 @@ def test_both_paths_give_identical_bytes(gpu_scenes):
 
 
 @pytest.mark.parametrize("name,w,h,spp", [("tenthousand", 96, 54, 16), ("spiral", 96, 54, 4), ("redchair", 64, 36, 32), ("tri", 128, 128, 0)])
-@pytest.mark.parametrize("traversal", [0, 1, 2])
-def test_every_traversal_mode_matches_its_oracle_mirror(name, w, h, spp, traversal, gpu_scenes, oracle_scenes):
+@pytest.mark.parametrize("traversal,qnodes", [(0, 1), (1, 1), (2, 1), (1, 2), (1, 0)])
+def test_every_traversal_mode_matches_its_oracle_mirror(name, w, h, spp, traversal, qnodes, gpu_scenes, oracle_scenes):
     """traversal 0 = node for node the reference's left-first walk, 1 = near child first where both subtrees hold spheres
-    only (default), 2 = near child first everywhere.  The oracle mirrors each: pixels within tolerance, visit counters equal."""
+    only (default), 2 = near child first everywhere; qnodes 2 = quantised records on every scene (the wide walk on redchair.txt and
+    tri.txt, which run on the exact records by default), 0 = never.  The oracle mirrors each: pixels within tolerance, visit
+    counters equal."""
     stl, raw = gpu_scenes(name)
-    with options(raw, traversal=traversal):
+    with options(raw, traversal=traversal, qnodes=qnodes):
         gu8, gf = gpu_render(raw, w, h, spp, counters=True)
         st = raw.stats()
-    flags = ol.product_flags(stl.num_triangles > 0, traversal=traversal)
+    flags = ol.product_flags(stl.num_triangles > 0, traversal=traversal, qnodes=qnodes)
     ref = oracle_scenes(name).render(w, h, spp, flags=flags, nthreads=8)
     check_image(gu8, gf, ref)
     for k in COUNTER_KEYS:

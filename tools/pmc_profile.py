@@ -12,7 +12,11 @@ Run on the GPU box (gpurun); copy the JSON into profiles/.  Derived figures:
   l2_hit_rate        TCC_HIT_sum / (TCC_HIT_sum + TCC_MISS_sum)
   valu_issue_frac    SQ_INSTS_VALU x 4 issue cycles / (1024 SIMDs x launch cycles)
   active_lanes       SQ_THREAD_CYCLES_VALU / (SQ_ACTIVE_INST_VALU x 64)
-  hbm_bytes          2 x FETCH_SIZE + WRITE_SIZE (KB -> B; gfx950 tallies 128-B read requests as 64 B, MI355X_MICROARCH.md)
+  hbm_bytes          2 x FETCH_SIZE + WRITE_SIZE (KB -> B; gfx950 tallies 128-B read requests as 64 B, MI355X_MICROARCH.md) -- an UPPER bound for
+                     scattered record fetches: the guide validates the doubling for wide streaming reads only
+  rdreq (group)      TCC_EA0_RDREQ_sum / _32B_sum: the L2's read requests to the fabric and how many of them are 32-byte ones; the others are
+                     64-byte tallies that stand for 64 or 128 bytes -> hbm_read_bytes_low / _high bracket the truth; bench.py prices the LOW one
+The JSON records the git HEAD and a hash of csrc/ + this file: bench.py marks a counter block stale when the hash is not the tree's.
 """
 import argparse
 import collections
@@ -36,11 +40,30 @@ GROUPS = {
     "icache": "SQC_ICACHE_REQ SQC_ICACHE_HITS SQC_ICACHE_MISSES SQ_IFETCH",
     "mix": "SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS SQ_INSTS_SMEM SQ_INSTS_BRANCH SQ_INST_CYCLES_SALU",
     "wrreq": "TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum",      # write requests L2 -> memory, and how many of them are 64-byte ones
+    "rdreq": "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_REQ_sum",   # read requests L2 -> fabric by size; all requests the L2 received
 }
-DEFAULT_GROUPS = "ta,l1,l2,sq,fetch,write"
+DEFAULT_GROUPS = "ta,l1,l2,sq,fetch,write,rdreq"
 CLOCK_HZ = 2.4e9
 CUS = 256
 XCDS = 8          # GRBM_GUI_ACTIVE is summed over the eight XCDs: cycles of the launch = sum / 8
+
+
+def source_hash():
+    """sha256 over the kernel sources: a counter summary belongs to the build it was taken on (bench.py compares)."""
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "cuda_ray_tracer_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        h.update(f.encode())
+        h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def git_head():
+    try:
+        return subprocess.run(["git", "-C", ROOT, "rev-parse", "--short=12", "HEAD"], capture_output=True, text=True).stdout.strip() or None
+    except Exception:
+        return None
 
 
 def main():
@@ -102,7 +125,7 @@ def main():
             launches[k] = len(v)
         print(f"group {g}: rc={p.returncode} " + " ".join(f"{k}={raw[k]:.5g}" for k in agg), flush=True)
 
-    out = {"workload": workload, "kernel": args.kernel, "tag": args.tag,
+    out = {"workload": workload, "kernel": args.kernel, "tag": args.tag, "csrc_sha16": source_hash(), "git_head": git_head(),
            "command": "rocprofv3 --pmc <group> --output-format csv -- python3 " + " ".join([os.path.relpath(bench[1], ROOT)] + bench[2:]) + " (one pass per group)",
            "env": args.env, "per_launch": raw, "launches_averaged": launches, "kernel_ms_under_pmc": kernel_ms, "derived": {}}
     dv = out["derived"]
@@ -132,6 +155,14 @@ def main():
         dv["hbm_write_bytes"] = raw.get("WRITE_SIZE", 0.0) * 1024.0
         dv["hbm_bytes_per_launch"] = dv["hbm_read_bytes"] + dv["hbm_write_bytes"]
         out["hbm_bytes_per_launch"] = dv["hbm_bytes_per_launch"]
+    if "TCC_EA0_RDREQ_sum" in raw:
+        n, n32 = raw["TCC_EA0_RDREQ_sum"], raw.get("TCC_EA0_RDREQ_32B_sum", 0.0)
+        dv["rdreq"] = n
+        dv["rdreq_32B"] = n32
+        dv["hbm_read_bytes_low"] = 32.0 * n32 + 64.0 * (n - n32)        # every other request counted at the 64 bytes it is tallied as
+        dv["hbm_read_bytes_high"] = 32.0 * n32 + 128.0 * (n - n32)      # ... at 128 bytes (what the guide measured for wide streaming reads)
+        if "TCC_REQ_sum" in raw:
+            dv["l2_requests"] = raw["TCC_REQ_sum"]
     json.dump(out, open(args.out, "w"), indent=1)
     print(json.dumps(dv))
 
