@@ -13,13 +13,15 @@ it frees.  Rank 0 prints ONE JSON line.
 
 value        = rays of the whole frame / max-over-ranks wall time per frame  (Mrays/s; a ray = one hitNearest call with
                bounce != 0), counted by the kernel's counters variant in an untimed pass.
-roofline     = algorithmic bytes of rank 0's trace-kernel launch (64 B per internal-node visit + 16 B per sphere test
-               + 48 B per triangle test + 44 B per material fetch, all counted) / its mean duration from HIP events on
-               the launch stream, against 8 TB/s HBM.  The BVH of the bundled scenes lives in L1/L2, so this is delivered
-               node bandwidth, not DRAM utilisation: `measured_hbm_frac` (PMC traffic / kernel time / peak) and the
-               address-unit figures (`ta_busy`, `l1_requests_per_launch`, `ta_floor_ms`, `frac_of_ta_floor`,
-               `valu_issue_frac`) from the committed rocprofv3 --pmc passes (profiles/*pmc_trace_kernel*.json) say what
-               actually bounds the kernel.
+roofline     = the bytes of the records rank 0's trace-kernel launch requests -- internal-node visits x the record size of the walk
+               in use (32 B quantised records on a sphere-only scene, 64 B otherwise) + 16 B per sphere test + 48 B per triangle
+               test + 44 B per material fetch, all counted -- / the launch's mean duration from HIP events on its stream (one event
+               pair per launch; a frame of several slabs is several launches), against 8 TB/s HBM: `achieved`, `frac`.
+               `frac_contract` prices every node visit at SURVEY.md 8d's 64 B whatever the record (round 1-2's `frac`).  The BVH
+               of the bundled scenes lives in L1/L2, so both are delivered record bandwidth, not DRAM utilisation; what bounds the
+               kernel is in `limiter`: the busiest unit of the committed rocprofv3 --pmc passes of THIS build
+               (profiles/*pmc_trace_kernel*.json carry a hash of csrc/; a summary of another build is marked stale and not used
+               for `traffic`).
 configs      = (N = 1) the other BASELINE configurations on this GPU, a few frames each: spiral 1080p16, redchair 4K64,
                the synthetic 1 M spheres + 1 M triangles scene at 4K x 256 spp (whole frame on one GPU) -- ms/frame,
                Mrays/s, node visits per ray, algorithmic roofline fraction.
@@ -44,39 +46,73 @@ def algorithmic_bytes(st):
     return st["internal_visits"] * 64 + st["sphere_tests"] * 16 + st["tri_tests"] * 48 + st["mat_fetches"] * 44
 
 
+def source_hash():
+    from cuda_ray_tracer_amd import build as B
+    return B.source_hash()
+
+
 def committed_pmc(workload):
-    """The newest committed counter summary for this workload (tools/pmc_profile.py -> profiles/*pmc_trace_kernel*.json);
-    bench.py cannot run the profiler on itself."""
+    """The committed counter summary for this workload (tools/pmc_profile.py -> profiles/*pmc_trace_kernel*.json; bench.py cannot
+    run the profiler on itself): the newest one taken on THIS build (its csrc_sha16 is the tree's), else the newest one of any
+    build, which the caller then reports as stale.  Returns (file name, summary, stale)."""
+    sha = source_hash()
     best = None
     for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_trace_kernel*.json"))):
         try:
             d = json.load(open(f))
         except Exception:
             continue
-        if d.get("workload") == workload:
-            best = (os.path.basename(f), d)
+        if d.get("workload") != workload:
+            continue
+        fresh = d.get("csrc_sha16") == sha
+        if best is None or fresh or best[2]:
+            best = (os.path.basename(f), d, not fresh)
     return best
 
 
 def committed_limiter(workload):
     """What bounds the kernel on `workload`, from its committed counter passes (None when there are none): per launch of the
-    trace kernel (one slab of a frame that takes several)."""
+    trace kernel (one slab of a frame that takes several).  `bound` names the busiest unit; a summary taken on another build is
+    kept for orientation only and says so (`stale`)."""
     got = committed_pmc(workload)
     if not got:
         return None
-    name, d = got
+    name, d, stale = got
     dv = d.get("derived", {})
     # (per-launch duration from the launch's own cycle counter: a frame of several slabs is several launches)
     launch_ms = dv.get("gui_active_ms")
-    out = {"pmc_source": "profiles/" + name, "pmc_workload": d.get("workload"), "pmc_launch_ms": launch_ms}
-    for k_out, k_in in (("valu_issue_frac", "valu_issue_frac"), ("ta_busy", "ta_busy"), ("l1_hit_rate", "l1_hit_rate"), ("l2_hit_rate", "l2_hit_rate"),
-                        ("active_lanes_per_valu_inst", "active_lanes"), ("beyond_l2_bytes_per_launch", "hbm_bytes_per_launch")):
+    out = {"pmc_source": "profiles/" + name, "pmc_workload": d.get("workload"), "pmc_csrc_sha16": d.get("csrc_sha16"), "pmc_git_head": d.get("git_head"),
+           "stale": stale, "pmc_launch_ms": launch_ms}
+    for k_out, k_in in (("valu_issue_frac", "valu_issue_frac"), ("ta_busy", "ta_busy"), ("l1_requests_per_launch", "l1_requests"), ("ta_floor_ms", "ta_floor_ms"),
+                        ("l1_hit_rate", "l1_hit_rate"), ("l2_hit_rate", "l2_hit_rate"), ("active_lanes_per_valu_inst", "active_lanes"),
+                        ("wave_wait_frac", "wave_wait_frac"), ("beyond_l2_read_bytes_low", "hbm_read_bytes_low"),
+                        ("beyond_l2_read_bytes_high", "hbm_read_bytes_high"), ("beyond_l2_write_bytes", "hbm_write_bytes")):
         if k_in in dv:
             out[k_out] = dv[k_in]
-    if "hbm_bytes_per_launch" in dv and launch_ms:
-        out["beyond_l2_GBps"] = dv["hbm_bytes_per_launch"] / (launch_ms * 1e-3) / 1e9
-        out["measured_hbm_frac"] = out["beyond_l2_GBps"] / HBM_PEAK_GBS
+    if launch_ms:
+        w = dv.get("hbm_write_bytes", 0.0)
+        # read bytes by request size (tools/pmc_profile.py, group rdreq): a 64-byte tally stands for 64 or 128 bytes -> a bracket;
+        # the fraction claimed is the LOW one.  Summaries from before round 3 only have FETCH_SIZE (x 2: the HIGH reading).
+        if "hbm_read_bytes_low" in dv:
+            out["measured_hbm_frac"] = (dv["hbm_read_bytes_low"] + w) / (launch_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
+            out["measured_hbm_frac_high"] = (dv["hbm_read_bytes_high"] + w) / (launch_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
+            out["beyond_l2_bytes_per_launch"] = dv["hbm_read_bytes_low"] + w
+        elif "hbm_bytes_per_launch" in dv:
+            out["measured_hbm_frac_high"] = dv["hbm_bytes_per_launch"] / (launch_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
+            out["beyond_l2_bytes_per_launch"] = dv["hbm_bytes_per_launch"]
+        if "ta_floor_ms" in dv:
+            out["frac_of_ta_floor"] = dv["ta_floor_ms"] / launch_ms
+    units = {"valu_issue": out.get("valu_issue_frac"), "address_units": out.get("ta_busy"), "hbm": out.get("measured_hbm_frac")}
+    units = {k: v for k, v in units.items() if v is not None}
+    if units:
+        out["bound"] = max(units, key=units.get)
+        out["frac"] = units[out["bound"]]
     return out
+
+
+def record_bytes(st, node_bytes):
+    """Bytes of the records a launch requests: what its own record layout reads per counted event."""
+    return st["internal_visits"] * node_bytes + st["sphere_tests"] * 16 + st["tri_tests"] * 48 + st["mat_fetches"] * 44
 
 
 def cpu_baseline(scene_file, width, height, spp, step):
@@ -119,11 +155,16 @@ def time_config(m, api, torch, raw, w, h, spp, steps, label, options=None, pmc_w
         raw.set_option(k, v)
     del img
     ab = algorithmic_bytes(st)
-    kms = ks["trace_kernel_ms_mean"]
-    out = {"workload": label, "ms_per_frame": dt * 1e3, "trace_kernel_ms": kms, "Mrays_per_s": st["rays"] / dt / 1e6, "rays_per_frame": st["rays"],
-           "node_visits_per_ray": st["internal_visits"] / max(st["rays"], 1),
+    kms = ks["trace_kernel_ms_mean"]                     # per frame: the sum over the frame's trace launches
+    launches = max(ks.get("trace_launches", 1), 1)
+    rb = record_bytes(st, ks.get("node_record_bytes", 64))
+    out = {"workload": label, "ms_per_frame": dt * 1e3, "trace_kernel_ms": kms, "trace_launches_per_frame": launches,
+           "trace_kernel_ms_per_launch": kms / launches, "Mrays_per_s": st["rays"] / dt / 1e6, "rays_per_frame": st["rays"],
+           "rays_traversed_per_frame": st.get("rays_traversed"),
+           "node_visits_per_ray": st["internal_visits"] / max(st["rays"], 1), "node_record_bytes": ks.get("node_record_bytes", 64),
            "leaf_tests_per_ray": (st["sphere_tests"] + st["tri_tests"]) / max(st["rays"], 1),
-           "algorithmic_GBps": ab / (kms * 1e-3) / 1e9, "frac": ab / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS, "frames_timed": steps,
+           "requested_record_GBps": rb / (kms * 1e-3) / 1e9, "frac": rb / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+           "frac_contract": ab / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS, "frames_timed": steps,
            "options": options or {}}
     lim = committed_limiter(pmc_workload or label) if not options else None      # (counter passes exist for the default options only)
     if lim:
@@ -196,6 +237,7 @@ def main():
     # Frames in flight: consecutive frames go to alternating streams, each with its own part buffer and (on rank 0) its own
     # gather buffers and frame, so the next frame's workgroups fill the CUs the draining frame frees (the drain of a frame
     # is one lane's 16-bounce chain, ~8 ms of latency).
+    auto_fif = args.frames_in_flight <= 0 and not args.serial      # default: whichever of 1 / 2 frames in flight is faster here (calibrated below)
     nfl = args.frames_in_flight if args.frames_in_flight > 0 else 2       # 3 is ~3 % better over 24+ steps, worse over 10
     nfl = 1 if args.serial else max(1, min(4, nfl))
     streams = [torch.cuda.Stream(device=dev) for _ in range(nfl)]
@@ -216,8 +258,10 @@ def main():
             gather_ms.append(e1.elapsed_time(e2))
             pending[i] = None
 
+    active = [nfl]      # frames in flight in use (<= nfl)
+
     def step(timed=False):
-        i = frame_no[0] % nfl
+        i = frame_no[0] % active[0]
         frame_no[0] += 1
         if timed:
             collect(i)
@@ -242,7 +286,7 @@ def main():
     torch.cuda.synchronize()
     cst = raw.stats()
     cdev = torch.device("cpu") if rehearse else dev
-    counts = torch.tensor([cst[k] for k in ("rays", "internal_visits", "sphere_tests", "tri_tests", "mat_fetches", "samples")],
+    counts = torch.tensor([cst[k] for k in ("rays", "internal_visits", "sphere_tests", "tri_tests", "mat_fetches", "samples", "rays_traversed")],
                           dtype=torch.float64, device=cdev)
     if world > 1:
         dist.all_reduce(counts)
@@ -250,6 +294,27 @@ def main():
 
     for _ in range(args.warmup):
         step()
+    fif_ms = None
+    if auto_fif:
+        # untimed calibration: a whole frame on this kernel can be faster alone than overlapped with the next one (round 2: 24.2 vs
+        # 24.9 ms), a stripe share of it is not -- take whichever is faster on this box, every rank the same
+        fif_ms = {}
+        for k in (1, 2):
+            active[0] = k
+            for _ in range(2):
+                step()
+            torch.cuda.synchronize()
+            if world > 1:
+                dist.barrier()
+            tc = time.perf_counter()
+            for _ in range(6):
+                step()
+            torch.cuda.synchronize()
+            t = torch.tensor([time.perf_counter() - tc], dtype=torch.float64, device=torch.device("cpu") if rehearse else dev)
+            if world > 1:
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            fif_ms[k] = float(t.item()) / 6 * 1e3
+        active[0] = 1 if fif_ms[1] <= fif_ms[2] else 2
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -284,41 +349,31 @@ def main():
 
     if rank == 0:
         ms_per_step = dt / args.steps * 1e3
-        mean_kernel_ms = kst["trace_kernel_ms_mean"]        # HIP events around every timed frame's trace kernel, on its launch stream
+        mean_kernel_ms = kst["trace_kernel_ms_mean"]        # HIP events around every trace launch of the timed frames, on their launch stream
+        launches = max(kst.get("trace_launches", 1), 1)
+        node_bytes = kst.get("node_record_bytes", 64)
         my_bytes = algorithmic_bytes(cst)
-        achieved = my_bytes / (mean_kernel_ms * 1e-3) / 1e9
+        req_bytes = record_bytes(cst, node_bytes)
+        achieved = req_bytes / (mean_kernel_ms * 1e-3) / 1e9
         workload = f"{args.scene}.txt {W}x{H} {SPP}spp"
         roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                "traffic": None, "kernel": "trace_kernel", "kernel_ms": mean_kernel_ms,
-                "algorithmic_bytes_per_launch": int(my_bytes),
+                "traffic": None, "kernel": "trace_kernel", "kernel_ms": mean_kernel_ms / launches, "launches_per_frame": launches,
+                "requested_record_bytes_per_launch": int(req_bytes / launches), "node_record_bytes": node_bytes,
+                "frac_contract": my_bytes / (mean_kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                "algorithmic_bytes_per_launch_contract": int(my_bytes / launches),
                 "per_ray": {"internal_visits": cst["internal_visits"] / max(cst["rays"], 1),
                             "sphere_tests": cst["sphere_tests"] / max(cst["rays"], 1),
                             "tri_tests": cst["tri_tests"] / max(cst["rays"], 1)},
-                "note": "algorithmic bytes (SURVEY.md 8d: 64 B per internal-node visit) are delivered node bandwidth: the bundled scenes' BVH "
-                        "is served from L1/L2, so frac is not DRAM utilisation (measured_hbm_frac is); the kernel is bound by VALU issue and the "
-                        "address units (valu_issue_frac, ta_*)"}
-        # what the kernel actually requests: sphere-only scenes are traversed through 32-byte quantised node records
-        qn = stl.num_triangles == 0 and stl.num_prims > 1 and raw.get_option("qnodes") and raw.get_option("traversal") >= 1 and not raw.get_option("wavefront")
-        node_bytes = 32 if qn else 64
-        roof["node_record_bytes"] = node_bytes
-        roof["requested_record_bytes_per_launch"] = int(cst["internal_visits"] * node_bytes + cst["sphere_tests"] * 16 + cst["tri_tests"] * 48 + cst["mat_fetches"] * 44)
-        roof["requested_record_GBps"] = roof["requested_record_bytes_per_launch"] / (mean_kernel_ms * 1e-3) / 1e9
-        pmc = committed_pmc(workload) if world == 1 and pworld == 1 else None
-        if pmc:
-            name, d = pmc
-            dv = d.get("derived", {})
-            roof["traffic"] = d.get("hbm_bytes_per_launch")
-            roof["pmc_source"] = "profiles/" + name
-            roof["pmc_kernel_ms"] = d.get("kernel_ms_under_pmc")
-            if roof["traffic"] and roof["pmc_kernel_ms"]:
-                roof["measured_hbm_frac"] = roof["traffic"] / (roof["pmc_kernel_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS
-            for k_out, k_in in (("ta_busy", "ta_busy"), ("l1_requests_per_launch", "l1_requests"), ("ta_floor_ms", "ta_floor_ms"),
-                                ("l1_hit_rate", "l1_hit_rate"), ("l2_hit_rate", "l2_hit_rate"), ("valu_issue_frac", "valu_issue_frac"),
-                                ("active_lanes_per_valu_inst", "active_lanes"), ("wave_wait_frac", "wave_wait_frac")):
-                if k_in in dv:
-                    roof[k_out] = dv[k_in]
-            if "ta_floor_ms" in dv and roof["pmc_kernel_ms"]:
-                roof["frac_of_ta_floor"] = dv["ta_floor_ms"] / roof["pmc_kernel_ms"]
+                "note": "achieved / frac: bytes of the records the launch requests (node visits x node_record_bytes + 16 B per sphere test + 48 B per "
+                        "triangle test + 44 B per material fetch, all counted) / HIP-event kernel time / 8 TB/s; frac_contract prices a node visit "
+                        "at SURVEY.md 8d's 64 B whatever the record.  The bundled scenes' BVH is served from L1/L2, so neither is DRAM "
+                        "utilisation: `traffic` (bytes beyond the L2s per launch, request-size bracket's low end) and limiter.measured_hbm_frac are; "
+                        "what bounds the kernel is limiter.bound"}
+        lim = committed_limiter(workload) if world == 1 and pworld == 1 else None
+        if lim:
+            roof["limiter"] = lim
+            if not lim["stale"]:
+                roof["traffic"] = lim.get("beyond_l2_bytes_per_launch")
         out = {
             "metric": "Mrays/sec, tenthousand.txt 1080p@16spp" if (args.scene, W, H, SPP) == HEADLINE
                       else f"Mrays/sec, {args.scene}.txt {W}x{H}@{SPP}spp",
@@ -331,8 +386,8 @@ def main():
             "vs_baseline": None,
             "dtype": "f32",
             "data": "bundled scene file scenes/%s.txt (the reference's own input); no synthetic substitution" % args.scene,
-            "config": {"workload": workload, "rays_per_frame": int(total_rays),
-                       "samples_per_frame": int(counts[5].item()), "parallelism": f"image stripes x{world}" if world > 1 else (f"DIAGNOSTIC: part 0 of {pworld} stripe sets on one GPU" if pworld > 1 else "single GPU"), "frames_in_flight": nfl,
+            "config": {"workload": workload, "rays_per_frame": int(total_rays), "rays_traversed_per_frame": int(counts[6].item()),
+                       "samples_per_frame": int(counts[5].item()), "parallelism": f"image stripes x{world}" if world > 1 else (f"DIAGNOSTIC: part 0 of {pworld} stripe sets on one GPU" if pworld > 1 else "single GPU"), "frames_in_flight": active[0], "frames_in_flight_calibration_ms": fif_ms,
                        "stripe_rows": stripe_rows, "lbvh_build_ms": build_ms, "traversal": raw.get_option("traversal")},
             "roofline": roof,
         }
@@ -368,7 +423,8 @@ def main():
             c5 = time_config(m, api, torch, r5, 3840, 2160, args.config5_spp, 1, lab,
                              pmc_workload="synthetic 1M spheres + 1M triangles 3840x2160 8spp (BASELINE config 5 scene, one slab)")
             c5["lbvh_build_ms"] = b5
-            c5["note"] = "default traversal: near-child-first only where both subtrees hold spheres only -- bit-identical to the reference's order by construction"
+            c5["note"] = ("default options: wide quantised records (four grandchild boxes per step, the reference's order; a triangle hit the reference's "
+                          "walk may not reach re-walks the exact records) -- same bytes as the exact-record walk on every tested scene, counters == the oracle's mirror")
             extra.append(c5)
             c5b = time_config(m, api, torch, r5, 3840, 2160, args.config5_spp, 1, lab, options={"traversal": 2})
             c5b["lbvh_build_ms"] = b5

@@ -61,7 +61,8 @@ class Stats(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in ("samples", "rays", "shadow_rays", "internal_visits", "sphere_tests",
                                           "tri_tests", "mat_fetches", "max_stack", "overflow_events")] + \
                [("trace_kernel_ms", C.c_float), ("render_ms", C.c_float), ("build_ms", C.c_float), ("num_nodes", C.c_int32),
-                ("trace_kernel_ms_mean", C.c_float), ("frames_timed", C.c_int32)]
+                ("trace_kernel_ms_mean", C.c_float), ("frames_timed", C.c_int32), ("trace_launches", C.c_int32), ("node_record_bytes", C.c_int32),
+                ("rays_traversed", C.c_uint64)]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}

@@ -43,6 +43,17 @@ def _all_deps():
     return deps
 
 
+def source_hash():
+    """sha256[:16] over csrc/: names the build a counter summary (tools/pmc_profile.py) was taken on; bench.py compares."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in sorted(os.listdir(CSRC)):
+        h.update(f.encode())
+        with open(os.path.join(CSRC, f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
 def build(force=False, verbose=False):
     os.makedirs(OUT, exist_ok=True)
     hipcc = _hipcc()

@@ -275,6 +275,7 @@ void mirt_scene_destroy(MirtScene* sc)
     if (c.ev1) hipEventDestroy(c.ev1);
     if (c.ev2) hipEventDestroy(c.ev2);
     if (c.ev3) hipEventDestroy(c.ev3);
+    for (hipEvent_t e : c.slab_ev) hipEventDestroy(e);
   }
   rng_cache_free(&sc->rng);
   hipFree(sc->wf_state); hipFree(sc->wf_rays); hipFree(sc->wf_ctr);
@@ -344,22 +345,25 @@ int mirt_get_stats(MirtScene* sc, MirtStats* out)
     if (c.used && !c.timed) {
       MIRT_HIP(hipEventSynchronize(c.ev3));
       float ms = 0.0f;
-      MIRT_HIP(hipEventElapsedTime(&ms, c.ev1, c.ev2));
-      sc->trace_ms_sum += (c.wf_trace_ms >= 0.0f) ? c.wf_trace_ms : ms; sc->trace_frames += 1; c.timed = true;
+      int rc = trace_ms_of(c, &ms);
+      if (rc != MIRT_OK) return rc;
+      sc->trace_ms_sum += ms; sc->trace_frames += 1; c.timed = true;
     }
   }
   out->frames_timed = sc->trace_frames;
   out->trace_kernel_ms_mean = sc->trace_frames ? (float)(sc->trace_ms_sum / sc->trace_frames) : 0.0f;
   sc->trace_ms_sum = 0.0; sc->trace_frames = 0;
   mirt::RenderCtx& cx = *sc->last;
-  MIRT_HIP(hipEventElapsedTime(&out->trace_kernel_ms, cx.ev1, cx.ev2));
-  if (cx.wf_trace_ms >= 0.0f) out->trace_kernel_ms = cx.wf_trace_ms;
+  { int rc = trace_ms_of(cx, &out->trace_kernel_ms); if (rc != MIRT_OK) return rc; }
+  out->trace_launches = cx.launches;
+  out->node_record_bytes = cx.node_bytes;
   MIRT_HIP(hipEventElapsedTime(&out->render_ms, cx.ev0, cx.ev3));
   if (cx.counted) {
     unsigned long long c[8];
     MIRT_HIP(hipMemcpy(c, cx.counters, sizeof(c), hipMemcpyDeviceToHost));
     out->samples = c[0]; out->rays = c[1]; out->shadow_rays = c[2]; out->internal_visits = c[3];
     out->sphere_tests = c[4]; out->tri_tests = c[5]; out->mat_fetches = c[6]; out->max_stack = c[7];
+    MIRT_HIP(hipMemcpy(&out->rays_traversed, cx.counters + 11, sizeof(unsigned long long), hipMemcpyDeviceToHost));
   }
   out->overflow_events = sc->overflow_events;
   sc->overflow_events = 0;

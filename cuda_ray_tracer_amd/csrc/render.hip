@@ -97,7 +97,7 @@ __global__ void __launch_bounds__(TRACE_BLOCK, MIRT_WAVES_PER_SIMD) trace_kernel
   const uint32_t gid32 = blockIdx.x * (uint32_t)TRACE_BLOCK + (uint32_t)tid;
   const long long gid = (long long)gid32;
   const long long gthreads = (long long)(gridDim.x * (uint32_t)TRACE_BLOCK);
-  Counters cn = {0, 0, 0, 0, 0, 0, 0, 0};
+  Counters cn = {0, 0, 0, 0, 0, 0, 0, 0, 0};
 
   // Work distribution: the sample range is cut into chunks of 2^chunk_shift consecutive samples (16 pixels at 16 spp); a wave
   // takes the next chunk from a global counter whenever its local one is used up (one atomic per chunk), so waves that
@@ -332,9 +332,9 @@ __global__ void __launch_bounds__(TRACE_BLOCK, MIRT_WAVES_PER_SIMD) trace_kernel
 
   unsigned long long* const counters = COUNT ? ap->counters : nullptr;
   if (COUNT && counters) {
-    uint32_t v[8] = {cn.samples, cn.rays, cn.shadow_rays, cn.internal_visits, cn.sphere_tests, cn.tri_tests, cn.mat_fetches, cn.max_stack};
+    uint32_t v[9] = {cn.samples, cn.rays, cn.shadow_rays, cn.internal_visits, cn.sphere_tests, cn.tri_tests, cn.mat_fetches, cn.max_stack, cn.traversed};
 #pragma unroll
-    for (int k = 0; k < 8; ++k) {
+    for (int k = 0; k < 9; ++k) {
       unsigned long long x = v[k];
       if (k == 7) {
 #pragma unroll
@@ -343,7 +343,7 @@ __global__ void __launch_bounds__(TRACE_BLOCK, MIRT_WAVES_PER_SIMD) trace_kernel
       } else {
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) x += __shfl_xor(x, off);
-        if ((tid & 63) == 0) atomicAdd(&counters[k], x);
+        if ((tid & 63) == 0) atomicAdd(&counters[k == 8 ? 11 : k], x);      // ([8..10]: work counter, overflow events, scratch)
       }
     }
   }
@@ -649,8 +649,9 @@ static int render_impl(MirtScene* sc, const MirtRenderParams* p, void* d_rgba8, 
     MIRT_HIP(hipEventSynchronize(cx.ev3));
     if (!cx.timed) {   // fold the finished frame's trace-kernel time into the running mean (mirt_get_stats)
       float ms = 0.0f;
-      MIRT_HIP(hipEventElapsedTime(&ms, cx.ev1, cx.ev2));
-      sc->trace_ms_sum += (cx.wf_trace_ms >= 0.0f) ? cx.wf_trace_ms : ms; sc->trace_frames += 1; cx.timed = true;
+      int rc = trace_ms_of(cx, &ms);
+      if (rc != MIRT_OK) return rc;
+      sc->trace_ms_sum += ms; sc->trace_frames += 1; cx.timed = true;
     }
   }
   // workspace
@@ -763,7 +764,7 @@ static int render_impl(MirtScene* sc, const MirtRenderParams* p, void* d_rgba8, 
   cx.frame_id = ++sc->frame_seq;
   MIRT_HIP(hipEventRecord(cx.ev0, stream));
   if (sched) MIRT_HIP(hipMemsetAsync(cx.chunk_cost, 0, 4 * nchunks, stream));
-  if (count) MIRT_HIP(hipMemsetAsync(cx.counters, 0, 8 * sizeof(unsigned long long), stream));
+  if (count) { MIRT_HIP(hipMemsetAsync(cx.counters, 0, 8 * sizeof(unsigned long long), stream)); MIRT_HIP(hipMemsetAsync(cx.counters + 11, 0, sizeof(unsigned long long), stream)); }
   a.work_counter = cx.counters + 8;
   cx.wf_trace_ms = -1.0f;
   float wf_ms_total = 0.0f;
@@ -777,7 +778,12 @@ static int render_impl(MirtScene* sc, const MirtRenderParams* p, void* d_rgba8, 
   int P = 1, lg = 0;
   while (P < sample_count) { P <<= 1; ++lg; }
 
-  MIRT_HIP(hipEventRecord(cx.ev1, stream));      // (ev1..ev2 brackets every slab's trace kernel; with several slabs also the resolves between them)
+  MIRT_HIP(hipEventRecord(cx.ev1, stream));
+  // one event pair per trace launch: a call of several slabs reports the SUM of its launches, not a bracket that would take in
+  // the resolve kernels between them
+  while ((int)cx.slab_ev.size() < 2 * nslabs) { hipEvent_t e = nullptr; MIRT_HIP(hipEventCreate(&e)); cx.slab_ev.push_back(e); }
+  cx.launches = nslabs;
+  cx.node_bytes = (qn && notri) ? 32 : 64;
   for (int slab = 0; slab < nslabs; ++slab) {
     const long long p0 = (long long)slab * slab_pixels;
     const long long pn = (p0 + slab_pixels < npix ? p0 + slab_pixels : npix) - p0;
@@ -795,6 +801,7 @@ static int render_impl(MirtScene* sc, const MirtRenderParams* p, void* d_rgba8, 
       // does not wait for the kernel of slab k (the stream orders a copy after the kernel that used the same slot)
       RenderArgs* adev = cx.args_dev + (slab % MAX_SLAB_ARGS);
       MIRT_HIP(hipMemcpyAsync(adev, &a, sizeof(RenderArgs), hipMemcpyHostToDevice, stream));
+      MIRT_HIP(hipEventRecord(cx.slab_ev[2 * slab], stream));
       // one instantiation per form of the random-number tables (device_common.h, xw_init) and per node format
       {
         const bool t8 = a.needs_rng && a.rng.mode == 0 && a.rng.chunk_bits == 8;
@@ -813,6 +820,7 @@ static int render_impl(MirtScene* sc, const MirtRenderParams* p, void* d_rgba8, 
       }
     }
     MIRT_HIP(hipGetLastError());
+    if (!wavefront) MIRT_HIP(hipEventRecord(cx.slab_ev[2 * slab + 1], stream));
     if (slab == nslabs - 1) MIRT_HIP(hipEventRecord(cx.ev2, stream));
 
     ResolveArgs ra;
@@ -838,6 +846,19 @@ static int render_impl(MirtScene* sc, const MirtRenderParams* p, void* d_rgba8, 
   ++sc->frame_no;
   MIRT_HIP(hipEventRecord(cx.ev3, stream));
   cx.used = true; cx.counted = count; cx.timed = false; cx.stream = stream; sc->last = &cx;
+  return MIRT_OK;
+}
+
+// trace-kernel time of the context's last (finished) call: the sum over its launches
+int trace_ms_of(RenderCtx& cx, float* ms)
+{
+  *ms = 0.0f;
+  if (cx.wf_trace_ms >= 0.0f) { *ms = cx.wf_trace_ms; return MIRT_OK; }
+  for (int k = 0; k < cx.launches && 2 * k + 1 < (int)cx.slab_ev.size(); ++k) {
+    float t = 0.0f;
+    MIRT_HIP(hipEventElapsedTime(&t, cx.slab_ev[2 * k], cx.slab_ev[2 * k + 1]));
+    *ms += t;
+  }
   return MIRT_OK;
 }
 

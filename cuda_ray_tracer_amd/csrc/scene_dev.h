@@ -170,10 +170,13 @@ struct RenderCtx {
   float4* samples = nullptr; size_t samples_cap = 0;
   uint32_t* stack_spill = nullptr; size_t spill_cap = 0;
   float* pending = nullptr; size_t pending_cap = 0;
-  unsigned long long* counters = nullptr;  // device: [0..7] MirtStats counters, [8] work counter
+  unsigned long long* counters = nullptr;  // device: [0..7] MirtStats counters, [8] work counter, [9] overflow events, [10] scratch (mirt_get_stats), [11] rays traversed
   hipStream_t stream = nullptr;            // the stream this context's latest frame was issued on
   RenderArgs* args_dev = nullptr;          // this frame's RenderArgs in device memory
-  hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr, ev3 = nullptr;   // render start / trace start / trace end / render end
+  hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr, ev3 = nullptr;   // render start / first trace start / last trace end / render end
+  std::vector<hipEvent_t> slab_ev;         // start / end of every trace launch of the last call beyond the first (ev1 / ev2 serve a one-slab call)
+  int launches = 0;                        // trace launches of the last call
+  int node_bytes = 64;                     // record size of the walk the last call used
   bool used = false, counted = false, timed = true;
   // longest-first scheduling: this frame's per-chunk cost, and the hand-out orders computed from it (two buffers used in
   // turn, so that a frame still reading an order never sees it rewritten)
@@ -264,6 +267,7 @@ int get_tree(MirtScene* sc, MirtTreeNode* nodes, uint32_t* codes, MirtPrimRef* r
 int render(MirtScene* sc, const MirtRenderParams* p, void* d_rgba8, void* d_rgba_f32, hipStream_t stream);
 int scatter_part(const MirtRenderParams* p, const void* d_part, void* d_frame, hipStream_t stream);
 int64_t render_num_pixels(const MirtRenderParams* p);
+int trace_ms_of(RenderCtx& cx, float* ms);
 int probe_math(int device, int which, int n, const float* in, float* out);
 int probe_xorwow(int device, int spp, int nstreams, int draws, uint32_t* out);
 int ensure_rng_tables(RngCache* rc, int sample_tables, long long frame_pixels, hipStream_t stream, RngTablesDev* out, bool allow_larger);

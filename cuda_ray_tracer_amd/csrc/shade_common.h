@@ -274,7 +274,7 @@ MIRT_DEV bool sphere_hit(const float4 q, const f3& o, const f3& d, float& t, flo
   return !(!inside && tc < 0.0f) && !(!inside && (r * r) < d2);
 }
 
-struct Counters { uint32_t samples, rays, shadow_rays, internal_visits, sphere_tests, tri_tests, mat_fetches, max_stack; };
+struct Counters { uint32_t samples, rays, shadow_rays, internal_visits, sphere_tests, tri_tests, mat_fetches, max_stack, traversed; };
 
 // Everything a lane carries from one loop iteration to the next.
 struct Lane {
@@ -349,6 +349,7 @@ MIRT_DEV void start_ray(const Args& a, Lane& S, Counters& cn)
   S.cur = a.root_ref; S.sp = 0;
   // a shadow ray the plane already blocks needs no traversal (same boolean as draw.cu:347-352 / 365-370)
   S.trav = (a.root_ref != REF_NONE) && !(shadow && plane_id >= 0 && tplane < S.limit);
+  if (COUNT && S.trav) cn.traversed++;
 }
 
 MIRT_DEV void set_ray(Lane& S, const RayS& r) { S.o = r.o; S.d = r.d; S.bounce = r.bounce; }

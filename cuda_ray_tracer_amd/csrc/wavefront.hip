@@ -120,7 +120,7 @@ __global__ void __launch_bounds__(SBLOCK, MIRT_WF_SHADE_WAVES) wf_shade_kernel(c
   uint32_t* st = w.state;
   const bool valid = slot < pool;
   const int nlights = a.num_suns + a.num_bulbs;
-  Counters cn = {0, 0, 0, 0, 0, 0, 0, 0};
+  Counters cn = {0, 0, 0, 0, 0, 0, 0, 0, 0};
 
   Lane S;
   S.g = -1;
@@ -274,7 +274,7 @@ __global__ void __launch_bounds__(WBLOCK, MIRT_WF_WAVES_PER_SIMD) wf_trace_kerne
   const int pool = w.pool;
   uint32_t* st = w.state;
   const unsigned int nrays = (unsigned int)w.ctr[1];
-  Counters cn = {0, 0, 0, 0, 0, 0, 0, 0};
+  Counters cn = {0, 0, 0, 0, 0, 0, 0, 0, 0};
   const float tmin = 0.0001f;
 
   // per-lane ray + traversal state
@@ -347,6 +347,7 @@ __global__ void __launch_bounds__(WBLOCK, MIRT_WF_WAVES_PER_SIMD) wf_trace_kerne
           if (tplane >= (float)(INT_MAX - 10)) { tplane = INFINITY; plane_id = -1; }
           tbest = INFINITY; refbest = REF_NONE; cur = a.root_ref; sp = 0;
           trav = (a.root_ref != REF_NONE) && !(shadow && anyhit && plane_id >= 0 && tplane < limit);
+          if (COUNT && trav) cn.traversed++;
         }
       }
     }
@@ -428,9 +429,9 @@ __global__ void __launch_bounds__(WBLOCK, MIRT_WF_WAVES_PER_SIMD) wf_trace_kerne
   }
 
   if (COUNT && a.counters) {
-    uint32_t v[8] = {0, cn.rays, cn.shadow_rays, cn.internal_visits, cn.sphere_tests, cn.tri_tests, 0, cn.max_stack};
+    uint32_t v[9] = {0, cn.rays, cn.shadow_rays, cn.internal_visits, cn.sphere_tests, cn.tri_tests, 0, cn.max_stack, cn.traversed};
 #pragma unroll
-    for (int k = 1; k < 8; ++k) {
+    for (int k = 1; k < 9; ++k) {
       if (k == 6) continue;
       unsigned long long x = v[k];
       if (k == 7) {
@@ -440,7 +441,7 @@ __global__ void __launch_bounds__(WBLOCK, MIRT_WF_WAVES_PER_SIMD) wf_trace_kerne
       } else {
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) x += __shfl_xor(x, off);
-        if (lane == 0 && x) atomicAdd(&a.counters[k], x);
+        if (lane == 0 && x) atomicAdd(&a.counters[k == 8 ? 11 : k], x);
       }
     }
   }

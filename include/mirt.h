@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define MIRT_VERSION 2
+#define MIRT_VERSION 3
 
 typedef enum MirtStatus {
   MIRT_OK = 0,
@@ -196,6 +196,15 @@ typedef struct MirtStats {
   /* mean trace-kernel time over the frames finished since the previous mirt_get_stats call, and their number */
   float trace_kernel_ms_mean;
   int32_t frames_timed;
+  /* (version 3) launches of the trace kernel in the last render call (one per slab of at most 2^slab_log2 samples);
+   * trace_kernel_ms is the SUM of their durations (one HIP event pair per launch), not a bracket around them */
+  int32_t trace_launches;
+  /* bytes of one internal-node record of the walk the last render used: 64 (exact boxes, two children per record; also the wide
+   * quantised records: four grandchildren per record) or 32 (quantised records of a sphere-only scene) */
+  int32_t node_record_bytes;
+  /* with MIRT_RENDER_COUNTERS: rays that entered the BVH walk (`rays` counts the reference's hitNearest calls: a shadow ray towards
+   * a light the surface faces away from, or one an infinite plane already blocks, is answered without a walk) */
+  uint64_t rays_traversed;
 } MirtStats;
 /* Waits for every frame in flight, then reports (and resets the running mean).  mirt_render / mirt_render_accumulate never
  * report a capacity overflow themselves (they are asynchronous): poll this call after a render, or before using its image.  Up to four frames may be in flight on

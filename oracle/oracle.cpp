@@ -71,7 +71,7 @@ typedef struct {
 
 typedef struct {
   uint64_t samples, rays, shadow_rays, node_iters, internal_visits, sphere_tests, tri_tests,
-           mat_fetches, max_stack, prim_hits, overflow, qn_retraces;
+           mat_fetches, max_stack, prim_hits, overflow, qn_retraces, traversals;
 } OStats;
 
 typedef struct {
@@ -885,6 +885,7 @@ static Obj traverse_wide(Ctx& cx, const Ray& ray, float initial_t_max, bool earl
 
 static inline Obj traverse_any(Ctx& cx, const Ray& ray, float initial_t_max, bool early, float stop_below)
 {
+  if (!cx.sc->nodes.empty()) cx.st.traversals++;      /* rays that enter the BVH walk (MirtStats.rays_traversed) */
   if ((cx.flags & ORC_FLAG_WIDE) && (cx.flags & ORC_FLAG_QNODES) && cx.sc->refs.size() > 1) return traverse_wide(cx, ray, initial_t_max, early, stop_below);
   if (cx.flags & (ORC_FLAG_ORDERED | ORC_FLAG_ORDERED_ALL)) return traverse_ordered(cx, ray, initial_t_max, early, stop_below);
   return traverse(cx, ray, initial_t_max, early, stop_below);
@@ -1192,7 +1193,7 @@ static void stats_add(OStats* a, const OStats& b)
 {
   a->samples += b.samples; a->rays += b.rays; a->shadow_rays += b.shadow_rays; a->node_iters += b.node_iters;
   a->internal_visits += b.internal_visits; a->sphere_tests += b.sphere_tests; a->tri_tests += b.tri_tests;
-  a->mat_fetches += b.mat_fetches; a->prim_hits += b.prim_hits; a->overflow += b.overflow; a->qn_retraces += b.qn_retraces;
+  a->mat_fetches += b.mat_fetches; a->prim_hits += b.prim_hits; a->overflow += b.overflow; a->qn_retraces += b.qn_retraces; a->traversals += b.traversals;
   if (b.max_stack > a->max_stack) a->max_stack = b.max_stack;
 }
 

@@ -62,7 +62,7 @@ NODE = np.dtype([("xmin", "<f4"), ("xmax", "<f4"), ("ymin", "<f4"), ("ymax", "<f
                  ("left", "<u4"), ("right", "<u4"), ("prim_offset", "<u4"), ("count", "<u4")])
 HIT = np.dtype([("t", "<f4"), ("kind", "<u4"), ("id", "<u4"), ("n", "<f4", 3)])
 STAT_FIELDS = ["samples", "rays", "shadow_rays", "node_iters", "internal_visits", "sphere_tests", "tri_tests",
-               "mat_fetches", "max_stack", "prim_hits", "overflow", "qn_retraces"]
+               "mat_fetches", "max_stack", "prim_hits", "overflow", "qn_retraces", "traversals"]
 
 
 class Stats(C.Structure):

@@ -27,7 +27,7 @@ def test_library_exports_every_declared_symbol():
     for s in syms:
         assert hasattr(L, s), s
     assert sorted(api.EXPORTS) == syms
-    assert L.mirt_version() == 2
+    assert L.mirt_version() == 3
 
 
 def test_exported_symbols_are_unmangled_c():

@@ -301,6 +301,7 @@ def test_every_traversal_mode_matches_its_oracle_mirror(name, w, h, spp, travers
     check_image(gu8, gf, ref)
     for k in COUNTER_KEYS:
         assert st[k] == ref["stats"][k], (k, st[k], ref["stats"][k])
+    assert st["rays_traversed"] == ref["stats"]["traversals"] <= st["rays"]
 
 
 REFERENCE_WALK = dict(traversal=0, shadow_anyhit=0, skip_unlit=0, qnodes=0)
@@ -324,6 +325,7 @@ def test_reference_walk_mode_is_the_plain_restatement_counter_for_counter(name, 
     check_image(gu8, gf, ref)
     for k in COUNTER_KEYS:
         assert st[k] == ref["stats"][k], (k, st[k], ref["stats"][k])
+    assert st["rays_traversed"] == ref["stats"]["traversals"] == st["rays"]      # this mode walks the BVH for every ray
     assert abs(st["rays"] / st["samples"] / rays_per_sample - 1) < 0.02
     assert abs((st["internal_visits"] + st["sphere_tests"] + st["tri_tests"]) / st["rays"] / iters - 1) < 0.02
     assert abs((st["sphere_tests"] + st["tri_tests"]) / st["rays"] / leaf - 1) < 0.02

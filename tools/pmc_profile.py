@@ -49,14 +49,9 @@ XCDS = 8          # GRBM_GUI_ACTIVE is summed over the eight XCDs: cycles of the
 
 
 def source_hash():
-    """sha256 over the kernel sources: a counter summary belongs to the build it was taken on (bench.py compares)."""
-    import hashlib
-    h = hashlib.sha256()
-    d = os.path.join(ROOT, "cuda_ray_tracer_amd", "csrc")
-    for f in sorted(os.listdir(d)):
-        h.update(f.encode())
-        h.update(open(os.path.join(d, f), "rb").read())
-    return h.hexdigest()[:16]
+    sys.path.insert(0, ROOT)
+    from cuda_ray_tracer_amd import build as B
+    return B.source_hash()
 
 
 def git_head():
