@@ -88,6 +88,7 @@ EXPORTS = [
     "mirt_scene_destroy", "mirt_scene_set_option", "mirt_scene_get_option", "mirt_build_lbvh", "mirt_render_num_pixels", "mirt_render", "mirt_render_accumulate", "mirt_finalize", "mirt_scatter_part",
     "mirt_get_stats", "mirt_get_tree", "mirt_probe_math", "mirt_probe_xorwow", "mirt_write_png",
     "mirt_multi_create", "mirt_multi_destroy", "mirt_multi_num_parts", "mirt_multi_set_option", "mirt_render_frame_multi",
+    "mirt_multi_submit", "mirt_multi_wait", "mirt_render_frames_multi", "mirt_multi_get_stats", "mirt_part_pixel_xy",
 ]
 
 _lib = None
@@ -138,6 +139,11 @@ def lib():
     L.mirt_multi_num_parts.argtypes = [C.c_void_p]
     L.mirt_multi_set_option.argtypes = [C.c_void_p, C.c_char_p, C.c_int]
     L.mirt_render_frame_multi.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.POINTER(MultiStats)]
+    L.mirt_multi_submit.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.POINTER(C.c_uint64)]
+    L.mirt_multi_wait.argtypes = [C.c_void_p, C.c_uint64, C.POINTER(MultiStats)]
+    L.mirt_render_frames_multi.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.POINTER(MultiStats), C.POINTER(C.c_float)]
+    L.mirt_multi_get_stats.argtypes = [C.c_void_p, C.c_int, C.POINTER(Stats)]
+    L.mirt_part_pixel_xy.argtypes = [C.POINTER(RenderParams), C.c_int64, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
     _lib = L
     return L
 
@@ -277,6 +283,13 @@ def freeRawConfigDeviceMemory(raw):
     raw.close()
 
 
+def part_pixel_xy(params, local):
+    """mirt_part_pixel_xy: frame coordinates of local pixel `local` of a part's compact buffer (host arithmetic, no GPU)."""
+    x, y = C.c_int32(0), C.c_int32(0)
+    _check(lib().mirt_part_pixel_xy(C.byref(params), local, C.byref(x), C.byref(y)))
+    return x.value, y.value
+
+
 class MultiGpu:
     """mirt_multi_*: one process, several GPUs, RCCL framebuffer gather (include/mirt.h)."""
 
@@ -298,6 +311,37 @@ class MultiGpu:
         _check(lib().mirt_render_frame_multi(self._h, width, height, spp, stripe_rows, out.ctypes.data, C.byref(st)))
         n = st.num_gpus
         return out, dict(num_gpus=n, build_ms=st.build_ms, render_ms=list(st.render_ms)[:n], gather_ms=st.gather_ms, frame_ms=st.frame_ms)
+
+    @staticmethod
+    def _stats(st):
+        n = st.num_gpus
+        return dict(num_gpus=n, build_ms=st.build_ms, render_ms=list(st.render_ms)[:n], gather_ms=st.gather_ms, frame_ms=st.frame_ms)
+
+    def submit(self, width, height, spp, stripe_rows=4, out=None):
+        """mirt_multi_submit: issues a frame, returns its ticket.  `out` (numpy uint8 [height, width, 4], kept alive by the caller
+        until wait) receives the frame."""
+        t = C.c_uint64(0)
+        _check(lib().mirt_multi_submit(self._h, width, height, spp, stripe_rows, out.ctypes.data if out is not None else None, C.byref(t)))
+        return t.value
+
+    def wait(self, ticket):
+        st = MultiStats()
+        _check(lib().mirt_multi_wait(self._h, ticket, C.byref(st)))
+        return self._stats(st)
+
+    def render_frames(self, width, height, spp, nframes, in_flight=2, stripe_rows=4):
+        """mirt_render_frames_multi: nframes frames back to back, `in_flight` of them in flight; (last frame, its stats, ms per frame)."""
+        import numpy as np
+        out = np.zeros((height, width, 4), np.uint8)
+        st = MultiStats()
+        ms = C.c_float(0)
+        _check(lib().mirt_render_frames_multi(self._h, width, height, spp, stripe_rows, nframes, in_flight, out.ctypes.data, C.byref(st), C.byref(ms)))
+        return out, self._stats(st), ms.value
+
+    def stats(self, part):
+        st = Stats()
+        _check(lib().mirt_multi_get_stats(self._h, part, C.byref(st)))
+        return st.as_dict()
 
     def close(self):
         if getattr(self, "_h", None):

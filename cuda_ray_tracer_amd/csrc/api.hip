@@ -297,6 +297,12 @@ int mirt_build_lbvh(MirtScene* sc, void* stream, float* build_ms)
 
 int64_t mirt_render_num_pixels(const MirtRenderParams* p) { return p ? render_num_pixels(p) : -1; }
 
+int mirt_part_pixel_xy(const MirtRenderParams* p, int64_t local, int32_t* x, int32_t* y)
+{
+  if (!p) { set_error("mirt_part_pixel_xy: null argument"); return MIRT_ERR_ARG; }
+  return part_pixel(p, local, x, y);
+}
+
 int mirt_render(MirtScene* sc, const MirtRenderParams* p, void* d_rgba8, void* d_rgba_f32, void* stream)
 {
   if (!sc || !p) { set_error("mirt_render: null argument"); return MIRT_ERR_ARG; }

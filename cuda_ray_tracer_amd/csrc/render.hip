@@ -447,15 +447,25 @@ __global__ void __launch_bounds__(TBLOCK) resolve_tree_kernel(const ResolveArgs 
   if (tid < ppb && lq < a.num_local_pixels) write_pixel(a, lq, sums[tid]);
 }
 
+// Local pixel lp of part `part_id`'s compact buffer -> its place in the frame: the part holds its stripes (stripe i = rows
+// [i stripe_rows, (i + 1) stripe_rows), owned by part i % num_parts) in increasing order, each row-major (include/mirt.h,
+// MirtRenderParams).  init_sample_core does the same arithmetic in 32 bits.
+__host__ __device__ inline void part_pixel_xy(long long lp, int width, int stripe_rows, int num_parts, int part_id, long long& x, long long& y)
+{
+  const long long stripe_pixels = (long long)stripe_rows * width;
+  const long long ls = lp / stripe_pixels, within = lp - ls * stripe_pixels;
+  const long long gs = ls * num_parts + part_id;
+  y = gs * stripe_rows + within / width;
+  x = within % width;
+}
+
 __global__ void __launch_bounds__(RBLOCK) scatter_kernel(const uchar4* __restrict__ part, uchar4* __restrict__ frame, long long n,
                                                          int width, int height, int stripe_rows, int num_parts, int part_id)
 {
   const long long lp = (long long)blockIdx.x * RBLOCK + threadIdx.x;
   if (lp >= n) return;
-  const long long stripe_pixels = (long long)stripe_rows * width;
-  const long long ls = lp / stripe_pixels, within = lp - ls * stripe_pixels;
-  const long long gs = ls * num_parts + part_id;
-  const long long y = gs * stripe_rows + within / width, x = within % width;
+  long long x, y;
+  part_pixel_xy(lp, width, stripe_rows, num_parts, part_id, x, y);
   frame[y * width + x] = part[lp];
 }
 
@@ -911,6 +921,16 @@ int scatter_part(const MirtRenderParams* p, const void* d_part, void* d_frame, h
 }
 
 int64_t render_num_pixels(const MirtRenderParams* p) { return local_pixels(p); }
+
+int part_pixel(const MirtRenderParams* p, int64_t local, int32_t* x, int32_t* y)
+{
+  const int64_t n = local_pixels(p);
+  if (n < 0 || local < 0 || local >= n || !x || !y) { set_error("mirt_part_pixel_xy: bad argument"); return MIRT_ERR_ARG; }
+  long long xx, yy;
+  part_pixel_xy(local, p->width, p->stripe_rows, p->num_parts, p->part, xx, yy);
+  *x = (int32_t)xx; *y = (int32_t)yy;
+  return MIRT_OK;
+}
 
 int probe_math(int device, int which, int n, const float* in, float* out)
 {

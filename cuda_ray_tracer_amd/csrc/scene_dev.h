@@ -267,6 +267,7 @@ int get_tree(MirtScene* sc, MirtTreeNode* nodes, uint32_t* codes, MirtPrimRef* r
 int render(MirtScene* sc, const MirtRenderParams* p, void* d_rgba8, void* d_rgba_f32, hipStream_t stream);
 int scatter_part(const MirtRenderParams* p, const void* d_part, void* d_frame, hipStream_t stream);
 int64_t render_num_pixels(const MirtRenderParams* p);
+int part_pixel(const MirtRenderParams* p, int64_t local, int32_t* x, int32_t* y);
 int trace_ms_of(RenderCtx& cx, float* ms);
 int probe_math(int device, int which, int n, const float* in, float* out);
 int probe_xorwow(int device, int spp, int nstreams, int draws, uint32_t* out);

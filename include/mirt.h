@@ -155,6 +155,9 @@ int mirt_render(MirtScene* sc, const MirtRenderParams* p, void* d_rgba8, void* d
 int mirt_render_accumulate(MirtScene* sc, const MirtRenderParams* p, void* d_accum_f32, int sample_first, int sample_count, void* stream);
 int mirt_finalize(const MirtRenderParams* p, const void* d_accum_f32, int total_samples, void* d_rgba8, void* stream);
 
+/* Where local pixel `local` of a part's compact buffer lies in the frame (host arithmetic: the mapping mirt_render,
+ * mirt_scatter_part and the multi-GPU gather use).  Returns MIRT_ERR_ARG when `local` is not a pixel of the part. */
+int mirt_part_pixel_xy(const MirtRenderParams* p, int64_t local, int32_t* x, int32_t* y);
 /* Scatter a compact part buffer back into a full row-major frame (device to device). */
 int mirt_scatter_part(const MirtRenderParams* p, const void* d_part_rgba8, void* d_frame_rgba8, void* stream);
 
@@ -173,13 +176,30 @@ typedef struct MirtMultiStats {
   float gather_ms;                         /* end of device 0's render -> frame re-interleaved on device 0 (includes waiting for the slowest peer) */
   float frame_ms;                          /* host wall clock of the call, host copy included */
 } MirtMultiStats;
-/* devices: ngpu device indices, or NULL for 0..ngpu-1.  Uploads and builds synchronously. */
+/* devices: ngpu device indices, or NULL for 0..ngpu-1.  Uploads and builds synchronously, all devices at once (one host thread
+ * each).  MIRT_MULTI_GATHER=copy in the environment: peer-to-peer copies instead of RCCL, and a device may be listed more than
+ * once (parts time-sharing a GPU: a rehearsal of the N > 1 path on a small box, never a scaling measurement). */
 int mirt_multi_create(const MirtSceneDesc* desc, int ngpu, const int* devices, MirtMulti** out);
 void mirt_multi_destroy(MirtMulti* mm);
 int mirt_multi_num_parts(const MirtMulti* mm);
 int mirt_multi_set_option(MirtMulti* mm, const char* name, int value);      /* mirt_scene_set_option on every device's scene */
-/* Renders one width x height frame at spp samples per pixel; host_rgba (nullable) receives width*height*4 bytes.  Synchronous. */
+/* Frames in flight: mirt_multi_submit issues one width x height frame at spp samples per pixel on every device and returns at
+ * once with a ticket; mirt_multi_wait blocks until that frame is gathered (and copied to host_rgba, nullable, which must stay
+ * valid until then).  Up to MIRT_MULTI_MAX_IN_FLIGHT frames may be in flight: consecutive frames overlap on every device (the
+ * next frame's waves take the slots the draining frame frees), the gathers run in submission order.  mirt_multi_wait returns
+ * MIRT_ERR_STATE when a capacity overflowed on any device (checked whenever no other frame is in flight; MirtStats.overflow_events). */
+#define MIRT_MULTI_MAX_IN_FLIGHT 4
+int mirt_multi_submit(MirtMulti* mm, int width, int height, int spp, int stripe_rows, uint8_t* host_rgba, uint64_t* ticket);
+int mirt_multi_wait(MirtMulti* mm, uint64_t ticket, MirtMultiStats* stats);
+/* One frame, synchronously (submit + wait). */
 int mirt_render_frame_multi(MirtMulti* mm, int width, int height, int spp, int stripe_rows, uint8_t* host_rgba, MirtMultiStats* stats);
+/* nframes frames back to back with `in_flight` of them in flight; host_rgba_last / last_stats (nullable) receive the last frame;
+ * ms_per_frame: host wall clock of the call / nframes. */
+int mirt_render_frames_multi(MirtMulti* mm, int width, int height, int spp, int stripe_rows, int nframes, int in_flight, uint8_t* host_rgba_last,
+                             MirtMultiStats* last_stats, float* ms_per_frame);
+/* mirt_get_stats of device `part`'s scene (waits for its frames in flight). */
+struct MirtStats;
+int mirt_multi_get_stats(MirtMulti* mm, int part, struct MirtStats* out);
 
 typedef struct MirtStats {
   /* filled by a render with MIRT_RENDER_COUNTERS */

@@ -93,3 +93,26 @@ def test_product_does_not_reference_the_oracle():
                 assert "oracle" not in txt.lower(), os.path.join(dirpath, f)
     needed = subprocess.check_output(["objdump", "-p", api.LIB_PATH]).decode()
     assert "liboracle" not in needed
+
+
+@pytest.mark.parametrize("nparts,width,height,rows", [(2, 7, 10, 4), (8, 5, 37, 4), (8, 3, 20, 1), (3, 4, 9, 2), (8, 6, 5, 4)])
+def test_part_pixel_arithmetic_tiles_the_frame_like_tiles_py(nparts, width, height, rows):
+    """mirt_render_num_pixels / mirt_part_pixel_xy -- the host side of the partition arithmetic mirt_multi_* and the kernels use
+    (scatter, sample -> pixel) -- against cuda_ray_tracer_amd/tiles.py's StripePartition for N = 2, 3, 8: every part's local
+    pixels, in order, are its stripes' rows; together they cover the frame exactly once (ragged last stripe, parts with no
+    stripe at all)."""
+    from cuda_ray_tracer_amd import api
+    from cuda_ray_tracer_amd.tiles import StripePartition
+    sp = StripePartition(width, height, rows, nparts)
+    seen = set()
+    for part in range(nparts):
+        p = api.render_params(width, height, 1, rows, nparts, part)
+        n = api.num_pixels(p)
+        assert n == sp.num_pixels(part)
+        want = [(x, y) for y in sp.rows(part) for x in range(width)]
+        got = [api.part_pixel_xy(p, i) for i in range(n)]
+        assert got == want
+        seen.update(got)
+        with pytest.raises(api.MirtError):
+            api.part_pixel_xy(p, n)
+    assert seen == {(x, y) for y in range(height) for x in range(width)}
