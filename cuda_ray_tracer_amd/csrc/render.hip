@@ -144,8 +144,10 @@ __global__ void __launch_bounds__(TRACE_BLOCK, MIRT_WAVES_PER_SIMD) trace_kernel
       else advance<COUNT, QN, SPEC>(a, S, cn, gid, gthreads);
     }
     if (!exhausted) {
+      // lanes without a sample take new ones -- once init_k of them wait, or when the wave has nothing else to do: starting a
+      // sample (RNG stream set-up, camera ray) costs the wave the same instructions for one lane as for forty
       const unsigned long long need = __ballot(!S.trav && S.g < 0);
-      if (need) {
+      if (need && (__popcll(need) >= a.init_k || __ballot(S.trav || S.batch_pending) == 0)) {
         const int want = __popcll(need);
         const unsigned long long nsamples = (unsigned long long)a.num_samples;
         const unsigned long long chunk = 1ull << a.chunk_shift;
@@ -733,8 +735,14 @@ static int render_impl(MirtScene* sc, const MirtRenderParams* p, void* d_rgba8, 
   a.counters = count ? cx.counters : nullptr;
   a.overflow = cx.counters + 9;
   a.lds_depth = (opt.stack_lds_depth >= 0 && opt.stack_lds_depth <= STACK_LDS) ? opt.stack_lds_depth : STACK_LDS;   // tests force the spill path
-  a.refill_k = opt.refill_k > 0 ? opt.refill_k : (qn ? (notri ? 32 : 28) : 44);      // (measured: sphere-only 32, wide records on the 2 M-primitive scene 24-28, exact records 44)
+  // Thresholds of the two expensive divergent pieces of work, measured per kind of kernel (round 3, tools/r03_i.sh): lanes wait to
+  // shade until refill_k of them do, lanes without a sample until init_k of them do.  Sphere-only scenes 32 / 10; wide records
+  // (2 M-primitive scene) 28 / 8; exact records (redchair.txt: many one-ray samples) 52 / 48 -- refilling finished lanes at
+  // every shade phase (init_k = 1, rounds 1-2) cost redchair.txt 14 % of its frame, the sphere scenes 1.5 %.
+  a.refill_k = opt.refill_k > 0 ? opt.refill_k : (qn ? (notri ? 32 : 28) : 52);
   a.drain_lanes = opt.drain_lanes;
+  const int init_k = opt.init_k > 0 ? opt.init_k : (qn ? (notri ? 10 : 8) : 48);
+  a.init_k = init_k < a.refill_k ? init_k : a.refill_k;      // (<= refill_k: lanes waiting for a sample count as waiting in the loop header)
   a.batch_k = opt.batch_k;
 
   // ---- longest-first chunk order (single-kernel path, one-slab calls) ------------------------------------------------

@@ -96,6 +96,7 @@ struct RenderArgs {
   int lds_depth;                  // traversal-stack entries kept in LDS (<= the compiled STACK_LDS); deeper ones spill
   int drain_lanes;                // a wave with at most this many live lanes and nothing left to fetch stops batching
   int batch_k;                    // start the next rays of ray batches when this many lanes wait for one
+  int init_k;                     // start new samples when this many lanes wait for one (or the wave has nothing else to do)
   unsigned long long* counters;   // MirtStats head (8 x u64) or null
   unsigned long long* overflow;   // never null: capacity overflows (traversal stack beyond 64, pending list), must stay 0
   unsigned long long* work_counter; // next unclaimed chunk of the frame (single-kernel path)
@@ -148,10 +149,9 @@ struct Options {
   int traversal = 1;           // MIRT_TRAVERSAL_*: 0 reference (left first), 1 ordered where pixels cannot change, 2 ordered everywhere
   int wavefront = 0;           // 1: the trace / shade kernel pair instead of the single kernel
   int stack_lds_depth = -1;    // traversal-stack entries kept in LDS (-1: the compiled size); tests force the spill path with it
-  int refill_k = 0;            // leave the traversal loop when this many lanes wait to shade; 0 = 32 with quantised nodes (sphere-only scenes:
-                               // tenthousand 23.9 / spiral 61.2 ms against 24.0 / 62.6 at 40 and 24.4 / 60.7 at 28), 44 otherwise (redchair 28.9
-                               // against 29.2 at 40)
+  int refill_k = 0;            // leave the traversal loop when this many lanes wait to shade; 0 = by kind of kernel (render.hip)
   int batch_k = 8, leaf_k = 8, reps = 4, drain_lanes = 16;
+  int init_k = 0;              // lanes without a sample are refilled once this many wait (1: at every shade phase); 0 = by kind of kernel (render.hip)
   int chunk_shift = 0;         // 0: by frame size
   int trace_waves = 0;         // 0: fill the device
   int shadow_anyhit = 1;       // 0: shadow rays are nearest-hit queries, as in diffuseLight (draw.cu:347-352, 365-370): the reference's walk, more node visits
