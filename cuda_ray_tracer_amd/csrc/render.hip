@@ -217,7 +217,7 @@ __global__ void __launch_bounds__(TRACE_BLOCK, MIRT_WAVES_PER_SIMD) trace_kernel
       const bool leaf = S.trav && (S.cur & REF_LEAF) != 0;
       const bool do_leaf = rep == 0 && do_leaf0;
       if (S.trav && (!leaf || do_leaf)) {
-        ++S.steps;
+        if (COUNT) ++S.steps;      // (scheduling statistic: the frames that measure their chunks run the counting kernels)
         // one record per step: a node (64 B: two child boxes + two child references) or a primitive (sphere 16 B,
         // triangle 48 B), addressed by one scalar base (the record heap) + a 32-bit byte offset.  Each kind loads the
         // quarters it needs inside its own branch: no merged/zero-filled registers between the two paths.
@@ -608,8 +608,8 @@ static int grid_blocks(int device)
 
 
 // One call of mirt_render / mirt_render_accumulate.  The part's pixels are rendered in slabs of at most 2^slab_log2 samples,
-// so the per-sample workspace is bounded (1 GiB by default) whatever the frame: BASELINE config 5 (3840x2160 x 256 spp,
-// 2.1 G samples) takes 32 slabs instead of a 34 GB buffer.  Each slab is a trace launch + a resolve launch; a slab boundary
+// so the per-sample workspace is bounded (4 GiB by default) whatever the frame: BASELINE config 5 (3840x2160 x 256 spp,
+// 2.1 G samples) takes 8 slabs instead of a 34 GB buffer.  Each slab is a trace launch + a resolve launch; a slab boundary
 // costs one drain of the persistent grid (~1-2 ms per 64 M samples).
 //   d_accum == null: pixels are written (mean, sRGB, quantise);  sample_first must be 0 and sample_count max(spp, 1)
 //   d_accum != null: the sum of each pixel's samples [sample_first, sample_first + sample_count) is ADDED to d_accum
@@ -737,9 +737,9 @@ static int render_impl(MirtScene* sc, const MirtRenderParams* p, void* d_rgba8, 
   a.lds_depth = (opt.stack_lds_depth >= 0 && opt.stack_lds_depth <= STACK_LDS) ? opt.stack_lds_depth : STACK_LDS;   // tests force the spill path
   // Thresholds of the two expensive divergent pieces of work, measured per kind of kernel (round 3, tools/r03_i.sh): lanes wait to
   // shade until refill_k of them do, lanes without a sample until init_k of them do.  Sphere-only scenes 32 / 10; wide records
-  // (2 M-primitive scene) 28 / 8; exact records (redchair.txt: many one-ray samples) 52 / 48 -- refilling finished lanes at
+  // (2 M-primitive scene) 24 / 8; exact records (redchair.txt: many one-ray samples) 52 / 48 -- refilling finished lanes at
   // every shade phase (init_k = 1, rounds 1-2) cost redchair.txt 14 % of its frame, the sphere scenes 1.5 %.
-  a.refill_k = opt.refill_k > 0 ? opt.refill_k : (qn ? (notri ? 32 : 28) : 52);
+  a.refill_k = opt.refill_k > 0 ? opt.refill_k : (qn ? (notri ? 32 : 24) : 52);
   a.drain_lanes = opt.drain_lanes;
   const int init_k = opt.init_k > 0 ? opt.init_k : (qn ? (notri ? 10 : 8) : 48);
   a.init_k = init_k < a.refill_k ? init_k : a.refill_k;      // (<= refill_k: lanes waiting for a sample count as waiting in the loop header)
@@ -764,24 +764,28 @@ static int render_impl(MirtScene* sc, const MirtRenderParams* p, void* d_rgba8, 
     for (uint32_t*& o : cx.order_out) MIRT_HIP(hipMalloc(&o, 4 * nchunks));
     cx.chunk_cap = nchunks;
   }
-  // the newest finished frame with the same sample count (and chunk size) provides the order; a frame that is still running does not
+  // The newest finished frame with the same sample count (and chunk size) that MEASURED its chunks provides the order; a frame
+  // that is still running does not.  The scene is immutable and samples are seeded by pixel and sample index only, so a frame's
+  // chunk costs are the same every time: once an order exists for this frame size it is reused, and the frame neither stamps
+  // costs nor sorts them again (the sort took 0.34 ms of a 24 ms frame, on the stream's critical path).
   const long long okey = slab_samples_max * 16 + chunk_shift;
   const uint32_t* order = nullptr;
   if (sched) {
     unsigned long long best = 0;
     for (int i = 0; i < MIRT_MAX_FRAMES; ++i) {
       RenderCtx& c = sc->ctx[i];
-      if (&c == &cx || !c.used || c.order_key != okey || c.frame_id <= best) continue;
-      if (hipEventQuery(c.ev3) != hipSuccess) continue;
-      best = c.frame_id; order = c.order_out[(c.uses - 1) % RenderCtx::ORDER_BUFS];
+      if (&c == &cx || !c.used || c.order_key != okey || c.order_frame <= best) continue;
+      if (hipEventQuery(c.order_ev) != hipSuccess) continue;
+      best = c.order_frame; order = c.order_out[(c.order_writes - 1) % RenderCtx::ORDER_BUFS];
     }
-    if (!order && cx.used && cx.order_key == okey) order = cx.order_out[(cx.uses - 1) % RenderCtx::ORDER_BUFS];   // cx's own previous frame (finished: synchronised above)
+    if (!order && cx.used && cx.order_key == okey) order = cx.order_out[(cx.order_writes - 1) % RenderCtx::ORDER_BUFS];   // cx's own earlier frame (finished: synchronised above)
   }
+  const bool measure = sched && !order;
   a.chunk_order = order;
-  a.chunk_cost = sched ? cx.chunk_cost : nullptr;
+  a.chunk_cost = measure ? cx.chunk_cost : nullptr;
   cx.frame_id = ++sc->frame_seq;
   MIRT_HIP(hipEventRecord(cx.ev0, stream));
-  if (sched) MIRT_HIP(hipMemsetAsync(cx.chunk_cost, 0, 4 * nchunks, stream));
+  if (measure) MIRT_HIP(hipMemsetAsync(cx.chunk_cost, 0, 4 * nchunks, stream));
   if (count) { MIRT_HIP(hipMemsetAsync(cx.counters, 0, 8 * sizeof(unsigned long long), stream)); MIRT_HIP(hipMemsetAsync(cx.counters + 11, 0, sizeof(unsigned long long), stream)); }
   a.work_counter = cx.counters + 8;
   cx.wf_trace_ms = -1.0f;
@@ -791,7 +795,7 @@ static int render_impl(MirtScene* sc, const MirtRenderParams* p, void* d_rgba8, 
   h.planes = a.planes; h.num_planes = a.num_planes; h.suns = a.suns; h.num_suns = a.num_suns; h.bulbs = a.bulbs; h.num_bulbs = a.num_bulbs; h.shadow_anyhit = a.shadow_anyhit;
   h.stack_spill = a.stack_spill; h.lds_depth = a.lds_depth; h.refill_k = a.refill_k; h.batch_k = a.batch_k; h.drain_lanes = a.drain_lanes;
   h.leaf_k = opt.leaf_k;
-  h.reps = opt.reps;
+  h.reps = opt.reps > 0 ? opt.reps : ((qn && !notri) ? 5 : 4);      // (wide records: 5 is 1 % better on the 2 M-primitive scene, worse elsewhere)
   if (!wavefront && !cx.args_dev) MIRT_HIP(hipMalloc(&cx.args_dev, sizeof(RenderArgs) * MAX_SLAB_ARGS));
   int P = 1, lg = 0;
   while (P < sample_count) { P <<= 1; ++lg; }
@@ -830,7 +834,7 @@ static int render_impl(MirtScene* sc, const MirtRenderParams* p, void* d_rgba8, 
 #define MIRT_LAUNCH_Q(C) do { if (qn && notri && nobulb && nopend) MIRT_LAUNCH_T(C, true, SPEC_NOTRI | SPEC_NOBULB | SPEC_NOPEND); \
                               else if (qn && notri) MIRT_LAUNCH_T(C, true, SPEC_NOTRI); \
                               else if (qn) MIRT_LAUNCH_S(C, true); else MIRT_LAUNCH_S(C, false); } while (0)
-        if (count) MIRT_LAUNCH_Q(true); else MIRT_LAUNCH_Q(false);
+        if (count || measure) MIRT_LAUNCH_Q(true); else MIRT_LAUNCH_Q(false);      // (measure: cost stamps need the step counter)
 #undef MIRT_LAUNCH_Q
 #undef MIRT_LAUNCH_S
 #undef MIRT_LAUNCH_T
@@ -852,14 +856,17 @@ static int render_impl(MirtScene* sc, const MirtRenderParams* p, void* d_rgba8, 
     }
     MIRT_HIP(hipGetLastError());
   }
-  if (sched) {
-    // order for later frames.  It overwrites the buffer this context wrote three uses (12 frames) ago; every frame that
-    // could have read that one has finished -- the host waited for each of them when it reused their contexts.
-    uint32_t* out = cx.order_out[cx.uses % RenderCtx::ORDER_BUFS];
+  if (measure) {
+    // order for later frames.  It overwrites the buffer this context wrote three orders ago; every frame that could have read
+    // that one has finished -- the host waited for each of them when it reused their contexts.
+    uint32_t* out = cx.order_out[cx.order_writes % RenderCtx::ORDER_BUFS];
     hipLaunchKernelGGL(order_kernel, dim3(1), dim3(SORT_BINS), 0, stream, cx.chunk_cost, (uint32_t)nchunks, out);
     MIRT_HIP(hipGetLastError());
+    MIRT_HIP(hipEventRecord(cx.order_ev, stream));
     cx.order_key = okey;
-  } else cx.order_key = -1;
+    cx.order_frame = cx.frame_id;
+    ++cx.order_writes;
+  }
   ++cx.uses;
   ++sc->frame_no;
   MIRT_HIP(hipEventRecord(cx.ev3, stream));

@@ -150,7 +150,8 @@ struct Options {
   int wavefront = 0;           // 1: the trace / shade kernel pair instead of the single kernel
   int stack_lds_depth = -1;    // traversal-stack entries kept in LDS (-1: the compiled size); tests force the spill path with it
   int refill_k = 0;            // leave the traversal loop when this many lanes wait to shade; 0 = by kind of kernel (render.hip)
-  int batch_k = 8, leaf_k = 8, reps = 4, drain_lanes = 16;
+  int batch_k = 8, leaf_k = 8, drain_lanes = 16;
+  int reps = 0;                // traversal steps per pass through the loop header; 0 = by kind of kernel (4; wide records 5)
   int init_k = 0;              // lanes without a sample are refilled once this many wait (1: at every shade phase); 0 = by kind of kernel (render.hip)
   int chunk_shift = 0;         // 0: by frame size
   int trace_waves = 0;         // 0: fill the device
@@ -160,7 +161,7 @@ struct Options {
                                // triangles of 65536 primitives or more (wide records, traversal = 1); 2 every scene
   int specialise = 1;          // kernels compiled without what the scene does not have: point lights; transparency and gi (SPEC_*, shade_common.h)
   int sched = 1;               // longest-first chunk order measured on earlier frames
-  int slab_log2 = 26;          // a call is rendered in slabs of at most 2^slab_log2 samples (1 GiB of per-sample workspace)
+  int slab_log2 = 28;          // a call is rendered in slabs of at most 2^slab_log2 samples (4 GiB of per-sample workspace; 2^26: +1.8 % on config 5)
   int wf_pool = 1 << 21, wf_refill_k = 16;
 };
 
@@ -189,7 +190,10 @@ struct RenderCtx {
   size_t chunk_cap = 0;
   unsigned uses = 0;
   unsigned long long frame_id = 0;         // sequence number of the frame that last used this context
-  long long order_key = -1;                // num_samples the order in order_out[(uses - 1) % ORDER_BUFS] was computed for
+  long long order_key = -1;                // frame size (and chunk size) the order in order_out[(order_writes - 1) % ORDER_BUFS] was measured on
+  unsigned order_writes = 0;               // orders this context has produced
+  unsigned long long order_frame = 0;      // frame_id of the frame that measured it
+  hipEvent_t order_ev = nullptr;           // ... and the end of its sort
   float wf_trace_ms = -1.0f;               // >= 0: the wavefront path ran; summed trace-kernel time
 };
 

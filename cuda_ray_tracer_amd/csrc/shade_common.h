@@ -657,7 +657,7 @@ MIRT_DEV void advance(const RenderArgs& a, Lane& S, Counters& cn, const long lon
     a.samples[S.g] = make_float4(S.L.x, S.L.y, S.L.z, S.alpha);
     // scheduling statistic: the chunk's most expensive sample.  A plain (possibly stale, never too large) load first: most
     // samples are not their chunk's maximum and issue no atomic (one atomic per sample was 0.76 GB of write traffic per frame)
-    if (a.chunk_cost) {
+    if (COUNT && a.chunk_cost) {
       uint32_t* cc = &a.chunk_cost[S.g >> a.chunk_shift];
       if (S.steps > *cc) atomicMax(cc, S.steps);
     }

@@ -98,18 +98,28 @@ void mirt_scene_destroy(MirtScene* sc);
  *                         near-child-first at nodes whose subtrees hold spheres only -- same pixels, fewer visits;
  *                         2 near-child-first everywhere (a triangle-silhouette sample may differ where the
  *                         reference's own result depends on its visiting order)
- *     "qnodes"            0/1 (default 1): sphere-only scenes are traversed through 32-byte quantised node records (two
- *                         memory requests per node visit instead of four; same pixels; not with traversal 0 / wavefront)
+ *     "qnodes"            0/1/2 (default 1): quantised node records in the single-kernel path.  1: sphere-only scenes walk 32-byte
+ *                         records (two memory requests per node visit instead of four; traversal >= 1); scenes with triangles of
+ *                         65536 primitives or more walk the wide records (the boxes of a node's four grandchildren per 64-byte
+ *                         record, two levels per step, the reference's order: traversal 1 only; a triangle hit the reference's
+ *                         walk may not reach sends its ray over the exact records again).  2: every scene.  0: never.  Same
+ *                         pixels in every case; not with wavefront
+ *     "shadow_anyhit"     0/1 (default 1): a shadow ray ends at its first occluder; 0: a nearest-hit query like every other ray,
+ *                         as diffuseLight does (draw.cu:347-352, 365-370) -- same boolean, more node visits
+ *     "skip_unlit"        0/1 (default 1): shadow rays towards lights the shading normal faces away from are not traced (their
+ *                         term is 0 either way, draw.cu:353-357); 0: every light's shadow ray is traced (draw.cu:342-374)
+ *                         {traversal 0, shadow_anyhit 0, skip_unlit 0, qnodes 0} is the reference's walk, ray for ray
  *     "specialise"        0/1 (default 1): a scene without point lights (and, sphere-only scenes, without transparent materials
  *                         and gi) is rendered by the kernel compiled without those features (same pixels and counters;
  *                         0: the general kernel)
  *     "wavefront"         0/1: the trace/shade kernel pair instead of the single kernel
- *     "slab_log2"         (default 26) a call is rendered in slabs of at most 2^slab_log2 samples: 16 B of workspace per
- *                         sample, i.e. 1 GiB, however large the frame
- *     "stack_lds_depth", "refill_k", "batch_k", "leaf_k", "reps", "drain_lanes", "chunk_shift", "trace_waves", "sched",
+ *     "slab_log2"         (default 28) a call is rendered in slabs of at most 2^slab_log2 samples: 16 B of workspace per
+ *                         sample, i.e. at most 4 GiB per frame in flight, however large the frame
+ *     "stack_lds_depth", "refill_k", "init_k", "batch_k", "leaf_k", "reps", "drain_lanes", "chunk_shift", "trace_waves", "sched",
  *     "wf_pool", "wf_refill_k": tuning (defaults are the measured optima)
- * Environment variables MIRT_<NAME> override the defaults once, when the scene is created; nothing reads the
- * environment during a render. */
+ * Environment variables MIRT_<NAME> override the defaults of the TUNING values once, when the scene is created (the mode
+ * switches -- bounds_as_shipped, traversal, wavefront, qnodes, shadow_anyhit, skip_unlit -- only with MIRT_ALLOW_ENV=1); nothing
+ * reads the environment during a render. */
 #define MIRT_TRAVERSAL_REFERENCE 0
 #define MIRT_TRAVERSAL_ORDERED 1
 #define MIRT_TRAVERSAL_ORDERED_ALL 2
