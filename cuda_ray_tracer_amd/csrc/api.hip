@@ -41,7 +41,7 @@ const OptionDesc OPTIONS[] = {
   {"traversal", &Options::traversal, 0, 2, true}, {"wavefront", &Options::wavefront, 0, 1, true},
   {"qnodes", &Options::qnodes, 0, 2, true}, {"shadow_anyhit", &Options::shadow_anyhit, 0, 1, true}, {"skip_unlit", &Options::skip_unlit, 0, 1, true},
   {"stack_lds_depth", &Options::stack_lds_depth, -1, 64, false}, {"refill_k", &Options::refill_k, 0, 64, false}, {"batch_k", &Options::batch_k, 1, 64, false},
-  {"leaf_k", &Options::leaf_k, 1, 64, false}, {"init_k", &Options::init_k, 0, 64, false}, {"reps", &Options::reps, 0, 8, false}, {"drain_lanes", &Options::drain_lanes, 0, 64, false},
+  {"leaf_k", &Options::leaf_k, 0, 64, false}, {"init_k", &Options::init_k, 0, 64, false}, {"reps", &Options::reps, 0, 8, false}, {"drain_lanes", &Options::drain_lanes, 0, 64, false},
   {"chunk_shift", &Options::chunk_shift, 0, 12, false}, {"trace_waves", &Options::trace_waves, 0, 1 << 20, false}, {"sched", &Options::sched, 0, 1, false},
   {"specialise", &Options::specialise, 0, 1, false}, {"slab_log2", &Options::slab_log2, 8, 30, false},
   {"wf_pool", &Options::wf_pool, 256, 1 << 24, false}, {"wf_refill_k", &Options::wf_refill_k, 1, 64, false},

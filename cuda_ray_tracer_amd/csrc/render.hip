@@ -794,7 +794,7 @@ static int render_impl(MirtScene* sc, const MirtRenderParams* p, void* d_rgba8, 
   h.nodes = a.nodes; h.root_ref = a.root_ref; h.swap_mask = a.swap_mask; h.qparams = a.qparams;
   h.planes = a.planes; h.num_planes = a.num_planes; h.suns = a.suns; h.num_suns = a.num_suns; h.bulbs = a.bulbs; h.num_bulbs = a.num_bulbs; h.shadow_anyhit = a.shadow_anyhit;
   h.stack_spill = a.stack_spill; h.lds_depth = a.lds_depth; h.refill_k = a.refill_k; h.batch_k = a.batch_k; h.drain_lanes = a.drain_lanes;
-  h.leaf_k = opt.leaf_k;
+  h.leaf_k = opt.leaf_k > 0 ? opt.leaf_k : (qn ? 8 : 4);      // (exact records, redchair.txt: 4 is 1.3 % better than 8)
   h.reps = opt.reps > 0 ? opt.reps : ((qn && !notri) ? 5 : 4);      // (wide records: 5 is 1 % better on the 2 M-primitive scene, worse elsewhere)
   if (!wavefront && !cx.args_dev) MIRT_HIP(hipMalloc(&cx.args_dev, sizeof(RenderArgs) * MAX_SLAB_ARGS));
   int P = 1, lg = 0;

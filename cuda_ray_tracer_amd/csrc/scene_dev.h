@@ -150,7 +150,8 @@ struct Options {
   int wavefront = 0;           // 1: the trace / shade kernel pair instead of the single kernel
   int stack_lds_depth = -1;    // traversal-stack entries kept in LDS (-1: the compiled size); tests force the spill path with it
   int refill_k = 0;            // leave the traversal loop when this many lanes wait to shade; 0 = by kind of kernel (render.hip)
-  int batch_k = 8, leaf_k = 8, drain_lanes = 16;
+  int batch_k = 8, drain_lanes = 16;
+  int leaf_k = 0;              // primitive tests are held back until this many lanes have one pending; 0 = by kind of kernel (8; exact records 4)
   int reps = 0;                // traversal steps per pass through the loop header; 0 = by kind of kernel (4; wide records 5)
   int init_k = 0;              // lanes without a sample are refilled once this many wait (1: at every shade phase); 0 = by kind of kernel (render.hip)
   int chunk_shift = 0;         // 0: by frame size
