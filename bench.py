@@ -295,6 +295,7 @@ def main():
     for _ in range(args.warmup):
         step()
     fif_ms = None
+    serial_kernel_ms = [None]
     if auto_fif:
         # untimed calibration: a whole frame on this kernel can be faster alone than overlapped with the next one (round 2: 24.2 vs
         # 24.9 ms), a stripe share of it is not -- take whichever is faster on this box, every rank the same
@@ -314,6 +315,10 @@ def main():
             if world > 1:
                 dist.all_reduce(t, op=dist.ReduceOp.MAX)
             fif_ms[k] = float(t.item()) / 6 * 1e3
+            if k == 1:
+                serial_kernel_ms[0] = raw.stats()["trace_kernel_ms_mean"]      # this rank's trace kernel with the GPU to itself
+            else:
+                raw.stats()
         active[0] = 1 if fif_ms[1] <= fif_ms[2] else 2
     if world > 1:
         dist.barrier()
@@ -369,6 +374,11 @@ def main():
                         "at SURVEY.md 8d's 64 B whatever the record.  The bundled scenes' BVH is served from L1/L2, so neither is DRAM "
                         "utilisation: `traffic` (bytes beyond the L2s per launch, request-size bracket's low end) and limiter.measured_hbm_frac are; "
                         "what bounds the kernel is limiter.bound"}
+        if serial_kernel_ms[0] and active[0] > 1:
+            # with frames in flight a launch shares the GPU with its neighbour: its duration says less about the kernel than the
+            # duration of the same launch alone (the calibration's serial frames)
+            roof["kernel_ms_alone"] = serial_kernel_ms[0] / launches
+            roof["frac_alone"] = req_bytes / (serial_kernel_ms[0] * 1e-3) / 1e9 / HBM_PEAK_GBS
         lim = committed_limiter(workload) if world == 1 and pworld == 1 else None
         if lim:
             roof["limiter"] = lim

@@ -164,7 +164,16 @@ __global__ void __launch_bounds__(TRACE_BLOCK, MIRT_WAVES_PER_SIMD) trace_kernel
               if (k < nchunks && a.chunk_order) k = a.chunk_order[k];
             }
             k = __shfl(k, 0);
-            if (k >= nchunks) { exhausted = true; break; }
+            if (k >= nchunks) {
+              // Every wave fetches past the end exactly once (and never again): the last one to do so puts both counters back
+              // to zero for the next launch on this context -- no memset between launches.
+              if (lane == 0 && atomicAdd(a.work_counter + 4, 1ull) == (unsigned long long)gridDim.x * (TRACE_BLOCK / 64) - 1ull) {
+                a.work_counter[4] = 0ull;
+                a.work_counter[0] = 0ull;
+              }
+              exhausted = true;
+              break;
+            }
             c_next = k << a.chunk_shift;
             c_end = (c_next + chunk < nsamples) ? c_next + chunk : nsamples;
           }
@@ -810,7 +819,8 @@ static int render_impl(MirtScene* sc, const MirtRenderParams* p, void* d_rgba8, 
     const long long p0 = (long long)slab * slab_pixels;
     const long long pn = (p0 + slab_pixels < npix ? p0 + slab_pixels : npix) - p0;
     a.pixel_base = p0; a.num_local_pixels = pn; a.num_samples = pn * sppe;
-    MIRT_HIP(hipMemsetAsync(cx.counters + 8, 0, sizeof(unsigned long long), stream));     // work counter ([9], the overflow events, is only reset by mirt_get_stats)
+    // (the work counter, counters[8], and the count of waves that ran past its end, counters[12], are left at zero by the launch
+    // itself; counters[9], the overflow events, is only reset by mirt_get_stats)
     if (wavefront) {
       a.refill_k = opt.wf_refill_k;
       float tms = 0.0f;
@@ -821,8 +831,13 @@ static int render_impl(MirtScene* sc, const MirtRenderParams* p, void* d_rgba8, 
     } else {
       // this slab's arguments: the kernel reads them from device memory; a ring of copies, so that the copy for slab k + 1
       // does not wait for the kernel of slab k (the stream orders a copy after the kernel that used the same slot)
-      RenderArgs* adev = cx.args_dev + (slab % MAX_SLAB_ARGS);
-      MIRT_HIP(hipMemcpyAsync(adev, &a, sizeof(RenderArgs), hipMemcpyHostToDevice, stream));
+      // (a frame like the one before it finds its arguments in place: nothing is copied)
+      const int slot = slab % MAX_SLAB_ARGS;
+      RenderArgs* adev = cx.args_dev + slot;
+      if (!cx.args_valid[slot] || memcmp(&cx.args_host[slot], &a, sizeof(RenderArgs)) != 0) {
+        MIRT_HIP(hipMemcpyAsync(adev, &a, sizeof(RenderArgs), hipMemcpyHostToDevice, stream));
+        cx.args_host[slot] = a; cx.args_valid[slot] = true;
+      }
       MIRT_HIP(hipEventRecord(cx.slab_ev[2 * slab], stream));
       // one instantiation per form of the random-number tables (device_common.h, xw_init) and per node format
       {

@@ -172,9 +172,11 @@ struct RenderCtx {
   float4* samples = nullptr; size_t samples_cap = 0;
   uint32_t* stack_spill = nullptr; size_t spill_cap = 0;
   float* pending = nullptr; size_t pending_cap = 0;
-  unsigned long long* counters = nullptr;  // device: [0..7] MirtStats counters, [8] work counter, [9] overflow events, [10] scratch (mirt_get_stats), [11] rays traversed
+  unsigned long long* counters = nullptr;  // device: [0..7] MirtStats counters, [8] work counter, [9] overflow events, [10] scratch (mirt_get_stats), [11] rays traversed, [12] waves past the end of the work
   hipStream_t stream = nullptr;            // the stream this context's latest frame was issued on
-  RenderArgs* args_dev = nullptr;          // this frame's RenderArgs in device memory
+  RenderArgs* args_dev = nullptr;          // this frame's RenderArgs in device memory (a ring of slots, one per slab in flight)
+  RenderArgs args_host[4];                 // what each slot holds
+  bool args_valid[4] = {false, false, false, false};
   hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr, ev3 = nullptr;   // render start / first trace start / last trace end / render end
   std::vector<hipEvent_t> slab_ev;         // start / end of every trace launch of the last call beyond the first (ev1 / ev2 serve a one-slab call)
   int launches = 0;                        // trace launches of the last call
