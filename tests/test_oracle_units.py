@@ -208,6 +208,38 @@ def test_the_mirror_equals_the_reference_walk_on_the_edge_scenes(scene, spp):
     assert plain["stats"]["rays"] == mirror["stats"]["rays"]
 
 
+@pytest.mark.parametrize("name,w,h,spp", [("redchair", 96, 54, 8), ("tri", 128, 128, 0), ("tenthousand", 48, 27, 4)])
+def test_quantised_and_wide_walks_give_the_image_of_the_reference_walk(name, w, h, spp, oracle_scenes):
+    """qnodes = 2 on the GPU side: the oracle's mirrors of the quantised walk on a scene with triangles (ORC_FLAG_QNODES: a
+    triangle hit the reference's walk may not reach re-walks the exact boxes) and of the wide walk (ORC_FLAG_WIDE: the boxes of a
+    node's four grandchildren per step, the reference's order) against the plain restatement: same float image bit for bit, same
+    rays; the wide walk takes about half the steps; the re-walk rule fires on redchair.txt's silhouettes and nowhere on a
+    sphere-only scene."""
+    o = oracle_scenes(name)
+    plain = o.render(w, h, spp, flags=0, nthreads=8)
+    q = o.render(w, h, spp, flags=ol.PRODUCT_FLAGS, nthreads=8)
+    wide = o.render(w, h, spp, flags=ol.PRODUCT_FLAGS_TRI, nthreads=8)
+    for m in (q, wide):
+        assert np.array_equal(plain["f32"].view(np.uint32), m["f32"].view(np.uint32))
+        assert plain["stats"]["rays"] == m["stats"]["rays"]
+    assert wide["stats"]["internal_visits"] < 0.75 * q["stats"]["internal_visits"]
+    assert wide["stats"]["qn_retraces"] == q["stats"]["qn_retraces"]
+    if name == "redchair":
+        assert q["stats"]["qn_retraces"] > 0
+    if name == "tenthousand":
+        assert q["stats"]["qn_retraces"] == 0
+
+
+def test_a_zero_direction_component_does_not_switch_an_axis_off_in_the_quantised_walk(oracle_scenes):
+    """redchair.txt's `sun 0 1 2` has a zero x component.  Rounds 1-2 ignored such an axis in the quantised box test (a superset,
+    so still exact) and every shadow ray of that sun then tested two axes only; the reciprocal is clamped instead.  The quantised
+    walk must stay within a few per cent of the exact boxes' node visits."""
+    o = oracle_scenes("redchair")
+    exact = o.render(96, 54, 4, flags=ol.PRODUCT_FLAGS_SMALL_TRI, nthreads=8)["stats"]
+    quant = o.render(96, 54, 4, flags=ol.PRODUCT_FLAGS, nthreads=8)["stats"]
+    assert exact["internal_visits"] <= quant["internal_visits"] < 1.08 * exact["internal_visits"]
+
+
 def test_tiles_and_threads_do_not_change_pixels(oracle_scenes):
     o = oracle_scenes("tenthousand")
     whole = o.render(50, 30, 16, nthreads=1)["f32"]
