@@ -42,7 +42,7 @@ const OptionDesc OPTIONS[] = {
   {"qnodes", &Options::qnodes, 0, 2, true}, {"shadow_anyhit", &Options::shadow_anyhit, 0, 1, true}, {"skip_unlit", &Options::skip_unlit, 0, 1, true},
   {"stack_lds_depth", &Options::stack_lds_depth, -1, 64, false}, {"refill_k", &Options::refill_k, 0, 64, false}, {"batch_k", &Options::batch_k, 1, 64, false},
   {"leaf_k", &Options::leaf_k, 0, 64, false}, {"init_k", &Options::init_k, 0, 64, false}, {"reps", &Options::reps, 0, 8, false}, {"drain_lanes", &Options::drain_lanes, 0, 64, false},
-  {"chunk_shift", &Options::chunk_shift, 0, 12, false}, {"trace_waves", &Options::trace_waves, 0, 1 << 20, false}, {"sched", &Options::sched, 0, 1, false},
+  {"chunk_shift", &Options::chunk_shift, 0, 12, false}, {"trace_waves", &Options::trace_waves, 0, 1 << 20, false}, {"sched", &Options::sched, 0, 2, false},
   {"specialise", &Options::specialise, 0, 1, false}, {"slab_log2", &Options::slab_log2, 8, 30, false},
   {"wf_pool", &Options::wf_pool, 256, 1 << 24, false}, {"wf_refill_k", &Options::wf_refill_k, 1, 64, false},
 };
@@ -240,6 +240,7 @@ int scene_create(const MirtSceneDesc* d, int device, MirtScene** out)
   if (rc == MIRT_OK) {
     hipError_t e = hipEventCreate(&sc->ev0);
     if (e == hipSuccess) e = hipEventCreate(&sc->ev1);
+    if (e == hipSuccess) e = hipEventCreate(&sc->so_ev);
     for (int i = 0; i < mirt::MIRT_MAX_FRAMES && e == hipSuccess; ++i) {
       e = hipEventCreate(&sc->ctx[i].ev0);
       if (e == hipSuccess) e = hipEventCreate(&sc->ctx[i].ev1);
@@ -285,6 +286,8 @@ void mirt_scene_destroy(MirtScene* sc)
   for (hipEvent_t e : sc->wf_events) hipEventDestroy(e);
   if (sc->ev0) hipEventDestroy(sc->ev0);
   if (sc->ev1) hipEventDestroy(sc->ev1);
+  if (sc->so_ev) hipEventDestroy(sc->so_ev);
+  hipFree(sc->so_order); hipFree(sc->so_keys); hipFree(sc->so_keys2); hipFree(sc->so_ws);
   delete sc;
 }
 

@@ -207,7 +207,7 @@ __global__ void __launch_bounds__(BLOCK) radix_pass_kernel(const uint32_t* __res
       const uint32_t digit = (key[it] >> shift) & 255u;
       const uint32_t pos = wcnt[wave][digit] + rank[it];
       keys_out[pos] = key[it];
-      vals_out[pos] = vals_in[idx];
+      vals_out[pos] = vals_in ? vals_in[idx] : (uint32_t)idx;      // (no values: the position itself)
     }
   }
 }
@@ -545,6 +545,20 @@ __global__ void __launch_bounds__(BLOCK) refit_pack_kernel(int n, const uint32_t
 }
 
 } // namespace
+
+// One stable radix pass over the low byte of the keys (render.hip orders a frame's samples by cost class with it): keys_out /
+// vals_out receive the keys and -- vals_in == null -- their original positions in ascending key order.  ws: 256 * nblocks + 256 words.
+size_t sort_low_byte_ws_words(long long n) { return 256 * (size_t)((n + SORT_TILE - 1) / SORT_TILE) + 256; }
+int sort_low_byte(const uint32_t* keys_in, uint32_t* keys_out, uint32_t* vals_out, long long n, uint32_t* ws, hipStream_t stream)
+{
+  const int sblocks = (int)((n + SORT_TILE - 1) / SORT_TILE);
+  uint32_t *hist = ws, *totals = ws + 256 * (size_t)sblocks;
+  hipLaunchKernelGGL(radix_pass_kernel<false>, dim3(sblocks), dim3(BLOCK), 0, stream, keys_in, (const uint32_t*)nullptr, keys_out, vals_out, hist, hist, totals, (int)n, 0, sblocks);
+  hipLaunchKernelGGL(row_scan_kernel, dim3(256), dim3(BLOCK), 0, stream, hist, totals, sblocks);
+  hipLaunchKernelGGL(radix_pass_kernel<true>, dim3(sblocks), dim3(BLOCK), 0, stream, keys_in, (const uint32_t*)nullptr, keys_out, vals_out, hist, hist, totals, (int)n, 0, sblocks);
+  MIRT_HIP(hipGetLastError());
+  return MIRT_OK;
+}
 
 int build_lbvh(MirtScene* sc, hipStream_t stream)
 {

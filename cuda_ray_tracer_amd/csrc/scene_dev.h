@@ -103,6 +103,8 @@ struct RenderArgs {
   const uint32_t* chunk_order;      // chunk k of the hand-out order is chunk chunk_order[k] of the frame (null: identity)
   int chunk_shift;                  // log2 of the number of consecutive samples a wave takes from the frame per atomic
   uint32_t* chunk_cost;             // per chunk: the largest number of traversal steps one of its samples took
+  const uint32_t* sample_order;     // sched = 2: position k of the hand-out is sample sample_order[k] of the launch (null: identity)
+  uint32_t* sample_key;             // sched = 2, measuring frame: per sample 255 - its cost class (sorted ascending: expensive first)
 };
 
 // What the traversal loop of the single-kernel path touches, passed by value (scalar registers).  Everything else is read
@@ -161,7 +163,7 @@ struct Options {
   int qnodes = 1;              // quantised node records in the single-kernel path: 0 never; 1 sphere-only scenes (traversal >= 1) and scenes with
                                // triangles of 65536 primitives or more (wide records, traversal = 1); 2 every scene
   int specialise = 1;          // kernels compiled without what the scene does not have: point lights; transparency and gi (SPEC_*, shade_common.h)
-  int sched = 1;               // longest-first chunk order measured on earlier frames
+  int sched = 2;               // longest-first hand-out measured on the first call of a shape: 2 by sample (stable within a cost class), 1 by chunk (one-slab calls), 0 off
   int slab_log2 = 28;          // a call is rendered in slabs of at most 2^slab_log2 samples (4 GiB of per-sample workspace; 2^26: +1.8 % on config 5)
   int wf_pool = 1 << 21, wf_refill_k = 16;
 };
@@ -256,6 +258,9 @@ struct MirtScene {
   unsigned long long* wf_ctr_host = nullptr;
   std::vector<hipEvent_t> wf_events;
   int wf_rounds = 0;
+  // sched = 2: the frame's samples in order of decreasing cost class, measured once per frame size (shared by the contexts)
+  uint32_t* so_order = nullptr; uint32_t* so_keys = nullptr; uint32_t* so_keys2 = nullptr; uint32_t* so_ws = nullptr;
+  size_t so_cap = 0, so_slab_cap = 0; long long so_key = -1, so_pending_key = -1; hipEvent_t so_ev = nullptr; bool so_busy = false;
   // rng tables cache
   mirt::RngCache rng;
   // LBVH build timing
@@ -269,6 +274,8 @@ namespace mirt {
 int hip_fail(hipError_t e, const char* what, const char* file, int line);
 // lbvh_build.hip
 int build_lbvh(MirtScene* sc, hipStream_t stream);
+size_t sort_low_byte_ws_words(long long n);
+int sort_low_byte(const uint32_t* keys_in, uint32_t* keys_out, uint32_t* vals_out, long long n, uint32_t* ws, hipStream_t stream);
 int get_tree(MirtScene* sc, MirtTreeNode* nodes, uint32_t* codes, MirtPrimRef* refs, float* bounds);
 // render.hip
 int render(MirtScene* sc, const MirtRenderParams* p, void* d_rgba8, void* d_rgba_f32, hipStream_t stream);

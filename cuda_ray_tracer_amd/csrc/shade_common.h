@@ -648,6 +648,16 @@ MIRT_DEV int advance_core(const RenderArgs& a, Lane& S, Counters& cn, const long
   return micro;
 }
 
+// Cost class of a sample for the longest-first hand-out (sched = 2): about four classes per doubling of its traversal steps; the
+// key sorts ascending, so 255 - class puts the expensive ones first.  0 steps (a bounce-0 frame): last.
+MIRT_DEV uint32_t cost_key(uint32_t steps)
+{
+  if (steps == 0) return 255u;
+  const int e = 31 - __clz((int)steps);
+  const uint32_t frac = e >= 2 ? (steps >> (e - 2)) & 3u : 0u;
+  return 255u - (uint32_t)(4 * e) - frac;
+}
+
 // Megakernel form: consume the finished trace, shade, and start the next ray of this lane (or finish the sample).
 template <bool COUNT, bool QN = false, int SPEC = 0>
 MIRT_DEV void advance(const RenderArgs& a, Lane& S, Counters& cn, const long long gid, const long long gthreads)
@@ -661,6 +671,7 @@ MIRT_DEV void advance(const RenderArgs& a, Lane& S, Counters& cn, const long lon
       uint32_t* cc = &a.chunk_cost[S.g >> a.chunk_shift];
       if (S.steps > *cc) atomicMax(cc, S.steps);
     }
+    if (COUNT && a.sample_key) a.sample_key[S.g] = cost_key(S.steps);
     S.g = -1;
     S.trav = false;
   } else if (micro == M_BATCH) {
@@ -717,6 +728,7 @@ MIRT_DEV void init_sample(const RenderArgs& a, Lane& S, Counters& cn, const long
   init_sample_core<COUNT, TABLES>(a, S, cn, idx);
   if (S.bounce == 0) {   // hitNearest: a ray with bounce 0 never hits (draw.cu:294)
     a.samples[idx] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    if (COUNT && a.sample_key) a.sample_key[idx] = 255u;
     S.g = -1;
     S.trav = false;
   } else {
