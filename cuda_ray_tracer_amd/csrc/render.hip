@@ -745,13 +745,16 @@ static int render_impl(MirtScene* sc, const MirtRenderParams* p, void* d_rgba8, 
   a.counters = count ? cx.counters : nullptr;
   a.overflow = cx.counters + 9;
   a.lds_depth = (opt.stack_lds_depth >= 0 && opt.stack_lds_depth <= STACK_LDS) ? opt.stack_lds_depth : STACK_LDS;   // tests force the spill path
-  // Thresholds of the two expensive divergent pieces of work, measured per kind of kernel (round 3, tools/r03_i.sh): lanes wait to
-  // shade until refill_k of them do, lanes without a sample until init_k of them do.  Sphere-only scenes 32 / 10; wide records
-  // (2 M-primitive scene) 24 / 8; exact records (redchair.txt: many one-ray samples) 52 / 48 -- refilling finished lanes at
+  // Thresholds of the two expensive divergent pieces of work, measured per kind of kernel (round 3, tools/r03_i.sh, r03_x.sh): lanes
+  // wait to shade until refill_k of them do, lanes without a sample until init_k of them do.  Sphere-only scenes 32 / 10; wide
+  // records (2 M-primitive scene) 24 / 8; exact records (redchair.txt) 64 / 64 -- with the samples handed out by cost class
+  // (sched = 2) the lanes of a wave run samples of one kind, and redchair.txt's short ray trees are fastest in lock step: the whole
+  // wave traverses, the whole wave shades, the whole wave takes 64 new samples (1080p16: 20.6 ms at 52 / 48, 18.1 at 64 / 64;
+  // tenthousand.txt's deep reflection chains want the opposite: 28.0 ms at 64 / 64 against 21.7).  Refilling finished lanes at
   // every shade phase (init_k = 1, rounds 1-2) cost redchair.txt 14 % of its frame, the sphere scenes 1.5 %.
-  a.refill_k = opt.refill_k > 0 ? opt.refill_k : (qn ? (notri ? 32 : 24) : 52);
+  a.refill_k = opt.refill_k > 0 ? opt.refill_k : (qn ? (notri ? 32 : 24) : 64);
   a.drain_lanes = opt.drain_lanes;
-  const int init_k = opt.init_k > 0 ? opt.init_k : (qn ? (notri ? 10 : 8) : 48);
+  const int init_k = opt.init_k > 0 ? opt.init_k : (qn ? (notri ? 10 : 8) : 64);
   a.init_k = init_k < a.refill_k ? init_k : a.refill_k;      // (<= refill_k: lanes waiting for a sample count as waiting in the loop header)
   a.batch_k = opt.batch_k;
 
