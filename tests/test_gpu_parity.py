@@ -488,6 +488,30 @@ def test_slabs_do_not_change_pixels_or_counters(gpu_scenes):
     assert np.array_equal(c8, d8) and np.array_equal(cf.view(np.uint32), df.view(np.uint32))
 
 
+@pytest.mark.parametrize("name,w,h,spp", [("tenthousand", 200, 120, 16), ("redchair", 160, 90, 32)])
+def test_the_hand_out_order_never_changes_a_byte(name, w, h, spp, gpu_scenes):
+    """sched = 2 (default): the first frame of a shape measures every sample's cost class (counting kernels + a stable one-byte
+    radix sort per launch) and later frames hand the samples out most expensive class first; sched = 1 does the same by chunk,
+    0 takes them in frame order.  Scheduling only: every frame of every mode -- the measuring one, the ordered ones, one-slab
+    and multi-slab calls, a stripe part, counters on or off -- gives the same bytes and the same counters."""
+    stl, raw = gpu_scenes(name)
+    with options(raw, sched=0):
+        a8, af = gpu_render(raw, w, h, spp, counters=True)
+        sa = raw.stats()
+    for sched in (2, 1):
+        for slab_log2 in (28, 12):
+            with options(raw, sched=sched, slab_log2=slab_log2):
+                for frame in range(3):                  # measure, (maybe unordered while the sort lands), ordered
+                    b8, bf = gpu_render(raw, w, h, spp, counters=(frame == 2))
+                    assert np.array_equal(a8, b8) and np.array_equal(af.view(np.uint32), bf.view(np.uint32)), (sched, slab_log2, frame)
+                sb = raw.stats()
+                for k in COUNTER_KEYS:
+                    assert sa[k] == sb[k], (sched, slab_log2, k)
+                p8, pf = gpu_render(raw, w, h, spp, stripe_rows=4, num_parts=3, part=1)      # another shape: measured afresh
+                q8, qf = gpu_render(raw, w, h, spp, stripe_rows=4, num_parts=3, part=1)
+                assert np.array_equal(p8, q8) and np.array_equal(pf.view(np.uint32), qf.view(np.uint32))
+
+
 def gpu_accumulate(raw, w, h, passes, total):
     acc = torch.zeros(w * h * 4, dtype=torch.float32, device="cuda")
     for first, count in passes:
