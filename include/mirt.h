@@ -115,7 +115,10 @@ void mirt_scene_destroy(MirtScene* sc);
  *     "wavefront"         0/1: the trace/shade kernel pair instead of the single kernel
  *     "slab_log2"         (default 28) a call is rendered in slabs of at most 2^slab_log2 samples: 16 B of workspace per
  *                         sample, i.e. at most 4 GiB per frame in flight, however large the frame
- *     "stack_lds_depth", "refill_k", "init_k", "batch_k", "leaf_k", "reps", "drain_lanes", "chunk_shift", "trace_waves", "sched",
+ *     "sched"             0/1/2 (default 2): longest-first hand-out of a call's samples, measured by the first call of a shape and reused
+ *                         (the scene is immutable): 2 by sample (every sample in its cost class, expensive classes first, positions
+ *                         within a class kept; 4 B per sample), 1 by chunk of 64..256 samples (one-slab calls), 0 frame order
+ *     "stack_lds_depth", "refill_k", "init_k", "batch_k", "leaf_k", "reps", "drain_lanes", "chunk_shift", "trace_waves",
  *     "wf_pool", "wf_refill_k": tuning (defaults are the measured optima)
  * Environment variables MIRT_<NAME> override the defaults of the TUNING values once, when the scene is created (the mode
  * switches -- bounds_as_shipped, traversal, wavefront, qnodes, shadow_anyhit, skip_unlit -- only with MIRT_ALLOW_ENV=1); nothing
