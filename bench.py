@@ -169,6 +169,9 @@ def time_config(m, api, torch, raw, w, h, spp, steps, label, options=None, pmc_w
     lim = committed_limiter(pmc_workload or label) if not options else None      # (counter passes exist for the default options only)
     if lim:
         out["limiter"] = lim
+    if out["frac"] > 1.0:
+        out["frac_note"] = ("above 1: the records this launch requests are answered by the L1 / L2s (a small tree, the lanes of a wave on samples of one "
+                            "kind), not by HBM -- delivered record bandwidth; limiter.bound names what the kernel is bound by")
     return out
 
 

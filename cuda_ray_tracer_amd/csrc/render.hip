@@ -805,9 +805,9 @@ static int render_impl(MirtScene* sc, const MirtRenderParams* p, void* d_rgba8, 
   a.sample_order = nullptr; a.sample_key = nullptr;
   if (by_sample) {
     order = nullptr;
-    const long long skey = okey ^ (total_samples << 20);
     if (sc->so_busy && hipEventQuery(sc->so_ev) == hipSuccess) sc->so_busy = false;      // the measurement in flight has landed
-    if (sc->so_key == skey && !sc->so_busy) ordered_samples = true;
+    // (the table is a permutation of every launch's sample range: valid for exactly this total and this slab size)
+    if (sc->so_key == okey && sc->so_total == total_samples && !sc->so_busy) ordered_samples = true;
     else if (!sc->so_busy) {
       // (no frame in flight reads the old table once every context's frame has finished: wait for them before rewriting it)
       for (int i = 0; i < MIRT_MAX_FRAMES; ++i) if (sc->ctx[i].used) MIRT_HIP(hipEventSynchronize(sc->ctx[i].ev3));
@@ -820,7 +820,7 @@ static int render_impl(MirtScene* sc, const MirtRenderParams* p, void* d_rgba8, 
       }
       measure_samples = true;
       sc->so_key = -1;
-      sc->so_pending_key = skey;
+      sc->so_pending_key = okey; sc->so_total = total_samples;
     }
   }
   const bool measure = (sched && !by_sample && !order) || measure_samples;

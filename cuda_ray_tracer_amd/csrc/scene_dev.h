@@ -260,7 +260,7 @@ struct MirtScene {
   int wf_rounds = 0;
   // sched = 2: the frame's samples in order of decreasing cost class, measured once per frame size (shared by the contexts)
   uint32_t* so_order = nullptr; uint32_t* so_keys = nullptr; uint32_t* so_keys2 = nullptr; uint32_t* so_ws = nullptr;
-  size_t so_cap = 0, so_slab_cap = 0; long long so_key = -1, so_pending_key = -1; hipEvent_t so_ev = nullptr; bool so_busy = false;
+  size_t so_cap = 0, so_slab_cap = 0; long long so_key = -1, so_pending_key = -1, so_total = -1; hipEvent_t so_ev = nullptr; bool so_busy = false;
   // rng tables cache
   mirt::RngCache rng;
   // LBVH build timing
