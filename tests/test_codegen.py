@@ -80,3 +80,13 @@ def test_refit_hand_off_keeps_its_write_through_stores_and_bypassing_loads():
         assert drained, ins[max(0, i - 8):i + 1]
     # no wider box stores sneaked in without the bit (the dwordx4 stores are the node record, which is only read by later kernels)
     assert not [t for t in ins if t.startswith(("global_store_dwordx2", "global_store_dwordx3"))]
+
+
+def test_the_diagnostic_patch_still_applies():
+    """tools/stamps.patch (per-wave time stamps: a diagnostic build kept OUT of the shipping sources) must keep applying to them."""
+    import shutil
+    import subprocess
+    if not os.path.isdir(os.path.join(ROOT, ".git")) or not shutil.which("git"):
+        pytest.skip("not a git checkout")
+    r = subprocess.run(["git", "-C", ROOT, "apply", "--check", os.path.join("tools", "stamps.patch")], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
