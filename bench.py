@@ -7,8 +7,8 @@ One step = one frame of the hot path (trace + resolve, scene and BVH resident in
 BASELINE.json's headline workload, `tenthousand.txt` at 1920x1080, 16 samples per pixel.  With N > 1 (launched by
 torch.distributed.run, one process per GPU) the frame is cut into interleaved row stripes, every rank renders its
 stripes with a replicated BVH, and the 8-bit framebuffer is gathered to rank 0 over RCCL and re-interleaved there; the
-total work per frame is fixed ("strong" scaling).  Consecutive frames are kept in flight on alternating streams (two per
-GPU; `--serial` for one): the drain of a frame is a single lane's bounce chain, and the next frame's workgroups use the CUs
+total work per frame is fixed ("strong" scaling).  Consecutive frames are kept in flight on alternating streams (one to
+three per GPU, whichever an untimed calibration finds fastest; `--serial` for one): the drain of a frame is a single lane's bounce chain, and the next frame's workgroups use the CUs
 it frees.  Rank 0 prints ONE JSON line.
 
 value        = rays of the whole frame / max-over-ranks wall time per frame  (Mrays/s; a ray = one hitNearest call with
@@ -241,7 +241,7 @@ def main():
     # gather buffers and frame, so the next frame's workgroups fill the CUs the draining frame frees (the drain of a frame
     # is one lane's 16-bounce chain, ~8 ms of latency).
     auto_fif = args.frames_in_flight <= 0 and not args.serial      # default: whichever of 1 / 2 frames in flight is faster here (calibrated below)
-    nfl = args.frames_in_flight if args.frames_in_flight > 0 else 2       # 3 is ~3 % better over 24+ steps, worse over 10
+    nfl = args.frames_in_flight if args.frames_in_flight > 0 else 3       # (auto: 1, 2 and 3 are calibrated below)
     nfl = 1 if args.serial else max(1, min(4, nfl))
     streams = [torch.cuda.Stream(device=dev) for _ in range(nfl)]
     gatherers = [FrameGatherer(partition, prank, pworld, dev) for _ in range(nfl)]
@@ -300,10 +300,11 @@ def main():
     fif_ms = None
     serial_kernel_ms = [None]
     if auto_fif:
-        # untimed calibration: a whole frame on this kernel can be faster alone than overlapped with the next one (round 2: 24.2 vs
-        # 24.9 ms), a stripe share of it is not -- take whichever is faster on this box, every rank the same
+        # untimed calibration: a whole frame on this kernel is faster alone than overlapped with the next one (round 3: 21.9 vs
+        # 23.3 ms), a stripe share of it is not (a 1/8 share: 3.21 / 2.93 / 2.89 ms at 1 / 2 / 3 in flight) -- take whichever is
+        # fastest on this box, every rank the same
         fif_ms = {}
-        for k in (1, 2):
+        for k in (1, 2, 3):
             active[0] = k
             for _ in range(2):
                 step()
@@ -322,7 +323,7 @@ def main():
                 serial_kernel_ms[0] = raw.stats()["trace_kernel_ms_mean"]      # this rank's trace kernel with the GPU to itself
             else:
                 raw.stats()
-        active[0] = 1 if fif_ms[1] <= fif_ms[2] else 2
+        active[0] = min(fif_ms, key=fif_ms.get)
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
