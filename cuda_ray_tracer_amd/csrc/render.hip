@@ -814,13 +814,21 @@ static int render_impl(MirtScene* sc, const MirtRenderParams* p, void* d_rgba8, 
       if (sc->so_cap < (size_t)total_samples || sc->so_slab_cap < (size_t)slab_samples_max) {
         hipFree(sc->so_order); hipFree(sc->so_keys); hipFree(sc->so_keys2); hipFree(sc->so_ws);
         sc->so_order = sc->so_keys = sc->so_keys2 = sc->so_ws = nullptr; sc->so_cap = 0; sc->so_slab_cap = 0; sc->so_key = -1;
-        MIRT_HIP(hipMalloc(&sc->so_order, 4 * (size_t)total_samples)); MIRT_HIP(hipMalloc(&sc->so_keys, 4 * (size_t)slab_samples_max));
-        MIRT_HIP(hipMalloc(&sc->so_keys2, 4 * (size_t)slab_samples_max)); MIRT_HIP(hipMalloc(&sc->so_ws, 4 * sort_low_byte_ws_words(slab_samples_max)));
-        sc->so_cap = (size_t)total_samples; sc->so_slab_cap = (size_t)slab_samples_max;
+        // (the table is an optimisation: without the memory for it the call is rendered in frame order)
+        const bool got = hipMalloc(&sc->so_order, 4 * (size_t)total_samples) == hipSuccess && hipMalloc(&sc->so_keys, 4 * (size_t)slab_samples_max) == hipSuccess &&
+                         hipMalloc(&sc->so_keys2, 4 * (size_t)slab_samples_max) == hipSuccess && hipMalloc(&sc->so_ws, 4 * sort_low_byte_ws_words(slab_samples_max)) == hipSuccess;
+        if (got) { sc->so_cap = (size_t)total_samples; sc->so_slab_cap = (size_t)slab_samples_max; }
+        else {
+          (void)hipGetLastError();
+          hipFree(sc->so_order); hipFree(sc->so_keys); hipFree(sc->so_keys2); hipFree(sc->so_ws);
+          sc->so_order = sc->so_keys = sc->so_keys2 = sc->so_ws = nullptr;
+        }
       }
-      measure_samples = true;
-      sc->so_key = -1;
-      sc->so_pending_key = okey; sc->so_total = total_samples;
+      if (sc->so_cap >= (size_t)total_samples && sc->so_slab_cap >= (size_t)slab_samples_max) {
+        measure_samples = true;
+        sc->so_key = -1;
+        sc->so_pending_key = okey; sc->so_total = total_samples;
+      }
     }
   }
   const bool measure = (sched && !by_sample && !order) || measure_samples;
