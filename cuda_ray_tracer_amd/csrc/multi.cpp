@@ -164,12 +164,12 @@ int mirt_multi_create(const MirtSceneDesc* desc, int ngpu, const int* devices, M
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { mirt::set_error("mirt_multi_create: no HIP device available (libmirt has no CPU path)"); return MIRT_ERR_NO_DEVICE; }
   const char* g = getenv("MIRT_MULTI_GATHER");
   const bool copy_gather = g && strcmp(g, "copy") == 0;
-  if (ngpu > ndev && !(copy_gather && devices)) { mirt::set_error("mirt_multi_create: more GPUs requested than present"); return MIRT_ERR_ARG; }
+  if (ngpu > ndev && !copy_gather) { mirt::set_error("mirt_multi_create: more GPUs requested than present"); return MIRT_ERR_ARG; }
   MirtMulti* mm = new MirtMulti();
   mm->n = ngpu;
   mm->copy_gather = copy_gather;
   for (int r = 0; r < ngpu; ++r) {
-    const int d = devices ? devices[r] : r;
+    const int d = devices ? devices[r] : (copy_gather ? r % ndev : r);      // (rehearsal: more parts than GPUs time-share them)
     if (d < 0 || d >= ndev) { mirt_multi_destroy(mm); mirt::set_error("mirt_multi_create: bad device index"); return MIRT_ERR_ARG; }
     // (RCCL refuses a device listed twice; with peer copies several parts may time-share one GPU: a rehearsal, see above)
     if (!copy_gather) for (int q = 0; q < r; ++q) if (mm->dev[q] == d) { mirt_multi_destroy(mm); mirt::set_error("mirt_multi_create: a device is listed twice"); return MIRT_ERR_ARG; }

@@ -191,7 +191,8 @@ typedef struct MirtMultiStats {
 } MirtMultiStats;
 /* devices: ngpu device indices, or NULL for 0..ngpu-1.  Uploads and builds synchronously, all devices at once (one host thread
  * each).  MIRT_MULTI_GATHER=copy in the environment: peer-to-peer copies instead of RCCL, and a device may be listed more than
- * once (parts time-sharing a GPU: a rehearsal of the N > 1 path on a small box, never a scaling measurement). */
+ * once -- or, with devices == NULL, ngpu may exceed the GPUs present (part r on GPU r mod their number): parts time-sharing a
+ * GPU, a rehearsal of the N > 1 path on a small box, never a scaling measurement. */
 int mirt_multi_create(const MirtSceneDesc* desc, int ngpu, const int* devices, MirtMulti** out);
 void mirt_multi_destroy(MirtMulti* mm);
 int mirt_multi_num_parts(const MirtMulti* mm);

@@ -107,6 +107,22 @@ def test_cli_renders_several_frames(tmp_path):
 
 
 @pytest.mark.gpu
+def test_cli_multi_gpu_branch_with_parts_sharing_one_gpu(tmp_path):
+    """`raytracer scene.txt --gpus 3 --frames 4` -- the CLI's mirt_multi_* branch (frames in flight, stripe parts, gather, per-frame
+    time) -- rehearsed on this one-GPU box with MIRT_MULTI_GATHER=copy (the three parts time-share GPU 0): same PNG bytes as the
+    single-GPU run."""
+    from PIL import Image
+    env = dict(os.environ, MIRT_MULTI_GATHER="copy")
+    r = subprocess.run([CLI, scene_path("tri"), "--width", "96", "--height", "70", "--spp", "4", "--gpus", "3", "--frames", "4", "--out", "m.png"],
+                       cwd=tmp_path, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300, env=env)
+    assert r.returncode == 0, r.stderr
+    assert re.search(r"GPUs: 3, frames: 4 \([0-9.]+ ms per frame\)", r.stdout), r.stdout
+    r1 = run([scene_path("tri"), "--width", "96", "--height", "70", "--spp", "4", "--out", "s.png"], tmp_path)
+    assert r1.returncode == 0, r1.stderr
+    assert np.array_equal(np.array(Image.open(tmp_path / "m.png")), np.array(Image.open(tmp_path / "s.png")))
+
+
+@pytest.mark.gpu
 def test_cli_scene_defaults_and_out_override(tmp_path, oracle_scenes):
     """No overrides: the scene's own size and aa (tri.txt: 100x100, aa 0); --out names the file; --traversal 0 is the
     reference's visiting order (same bytes)."""
