@@ -644,6 +644,13 @@ int build_lbvh(MirtScene* sc, hipStream_t stream)
   MIRT_HIP(hipEventRecord(sc->ev1, stream));
   MIRT_HIP(hipStreamSynchronize(stream));   // lbvh_builder.cu:475
   MIRT_HIP(hipEventElapsedTime(&sc->build_ms, sc->ev0, sc->ev1));
+  // the largest coordinate magnitude of the scene box, from the root record's two child boxes (HotArgs::reach_slack)
+  sc->coord_max = 0.0f;
+  if (n > 1) {
+    float rec[12];
+    MIRT_HIP(hipMemcpy(rec, sc->nodes, sizeof(rec), hipMemcpyDeviceToHost));
+    for (float v : rec) sc->coord_max = fmaxf(sc->coord_max, fabsf(v));
+  }
 
   // root: node 0, unless the whole scene is a single primitive
   sc->root_ref = (n == 1) ? (REF_LEAF | (sc->Nt ? REF_TRI : 0u) | (sc->prim_base / 16u)) : 0u;

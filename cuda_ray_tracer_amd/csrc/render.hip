@@ -130,6 +130,13 @@ __global__ void __launch_bounds__(TRACE_BLOCK, MIRT_WAVES_PER_SIMD) trace_kernel
     const RenderArgs* aq = ap;
     asm volatile("" : "+s"(aq));
     const RenderArgs& a = *aq;
+    // A lane whose nearest-hit walk ended on a sphere the reference may never have tested (hit_needs_literal_walk: a few rays per
+    // frame) has its ray walked again here, the reference's way, before the hit is shaded below -- while the sixteen parked words
+    // of the lane are still in LDS: with them in registers the walk's own pushed spills into the whole shade phase (+1..3 %).
+    // (the lanes vetted are exactly those the loop below lets advance() consume: none is looked at twice)
+    if (a.reach_check && !S.trav && S.g >= 0 && !(exhausted && S.batch_pending) && (!S.batch_pending || S.li >= a.num_suns + a.num_bulbs)) {
+      if (hit_needs_literal_walk<QN>(a, S)) walk_literally<COUNT, NOTRI>(a, S, cn, gid, gthreads);
+    }
     {
       const uint4 r0 = lds_rng[0][tid], r1 = lds_rng[1][tid];
       S.rng.v0 = r0.x; S.rng.v1 = r0.y; S.rng.v2 = r0.z; S.rng.v3 = r0.w;
@@ -254,7 +261,7 @@ __global__ void __launch_bounds__(TRACE_BLOCK, MIRT_WAVES_PER_SIMD) trace_kernel
           if (QN && !NOTRI && closer && tri && S.qsx != 0u) {
             f3 inv;
             if (!triangle_leaf_reached(ap, S.cur & REF_OFFMASK, S.o, S.d, t, tmin, inv)) {
-              // walk this ray again from the root, over the exact records (node 0 sits at heap offset 0)
+              // walk this ray again from the root, over the exact records (node 0 sits at heap offset 0), left child first
               closer = false;
               S.inv = inv; S.qsx = 0u;
               S.tos = 0u; S.sp = 1;      // (the pop below makes the root the current node)
@@ -314,7 +321,8 @@ __global__ void __launch_bounds__(TRACE_BLOCK, MIRT_WAVES_PER_SIMD) trace_kernel
             const uint4 ch = *reinterpret_cast<const uint4*>(nrec + 3);      // child references, NODE_SWAP_* flags
             box_pair(q0, q1, q2, S.o.x, S.o.y, S.o.z, S.inv.x, S.inv.y, S.inv.z, S.tbest, tmin, hl, hr, tel, ter);
             lref = ch.x; rref = ch.y;
-            order_children(hl, hr, tel, ter, ch.z, h.swap_mask, lref, rref);
+            // (with QN every lane in this branch is walking its ray again: the reference's order, left first)
+            if (!QN) order_children(hl, hr, tel, ter, ch.z, h.swap_mask, lref, rref);
           }
           // first child next, push the second (bvh_traversal.cu:149-157: left, right), written with selects: one short
           // branch for the push
@@ -845,6 +853,8 @@ static int render_impl(MirtScene* sc, const MirtRenderParams* p, void* d_rgba8, 
   h.nodes = a.nodes; h.root_ref = a.root_ref; h.swap_mask = a.swap_mask; h.qparams = a.qparams;
   h.planes = a.planes; h.num_planes = a.num_planes; h.suns = a.suns; h.num_suns = a.num_suns; h.bulbs = a.bulbs; h.num_bulbs = a.num_bulbs; h.shadow_anyhit = a.shadow_anyhit;
   h.stack_spill = a.stack_spill; h.lds_depth = a.lds_depth; h.refill_k = a.refill_k; h.batch_k = a.batch_k; h.drain_lanes = a.drain_lanes;
+  a.reach_check = ((qn || a.swap_mask != 0u) && sc->N > 1) ? 1 : 0;
+  a.reach_slack = 4.76837158203125e-07f * sc->coord_max;
   h.leaf_k = opt.leaf_k > 0 ? opt.leaf_k : (qn ? 8 : 4);      // (exact records, redchair.txt: 4 is 1.3 % better than 8)
   h.reps = opt.reps > 0 ? opt.reps : ((qn && !notri) ? 5 : 4);      // (wide records: 5 is 1 % better on the 2 M-primitive scene, worse elsewhere)
   if (!wavefront && !cx.args_dev) MIRT_HIP(hipMalloc(&cx.args_dev, sizeof(RenderArgs) * MAX_SLAB_ARGS));

@@ -75,6 +75,8 @@ struct RenderArgs {
   uint32_t root_ref;
   uint32_t prim_base16;           // offset of the primitive region in the heap, in 16-byte units
   uint32_t swap_mask;             // NODE_SWAP_* bits that allow near-child-first descent (0: the reference's left-first order)
+  int reach_check;                // the walk is not the reference's own (order or boxes): sphere hits are vetted before they are shaded (hit_needs_literal_walk)
+  float reach_slack;              // 2^-21 x the largest coordinate magnitude of the scene box
   int skip_unlit;                 // 1: shadow rays towards lights the shading normal faces away from are not traced (all colours finite)
   int shadow_anyhit;              // 1: a shadow ray ends at its first occluder; 0: nearest-hit query like every other ray (draw.cu:347-352)
   const float* qparams;           // quantised nodes in use: grid origin xyz, grid step xyz, 2^60 / grid step xyz (else null)
@@ -243,6 +245,7 @@ struct MirtScene {
   uint32_t root_ref = mirt::REF_NONE;
   bool built = false;
   float build_ms = 0.0f;
+  float coord_max = 0.0f;               // largest |coordinate| of the scene box (set by the build)
   // render workspaces: MIRT_MAX_FRAMES contexts so that several frames can be in flight on different streams (the next frame's blocks fill the
   // CUs the draining frame frees); a context is reused only after its previous frame has finished
   mirt::RenderCtx ctx[mirt::MIRT_MAX_FRAMES];

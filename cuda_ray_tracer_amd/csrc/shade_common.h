@@ -200,15 +200,10 @@ MIRT_DEV void quantised_axis(float gmin, float gstep, float lim, float o, float 
   sel = A >= 0.0f ? 0x07060100u : 0x07060302u;
 }
 
-// A sphere reached through quantised (larger) boxes skipped part of the box test its leaf gets in the reference's walk.  For a
-// sphere that is hit, that test (bvh_traversal.cu:11-44) can only fail through its `t_exit > t_min` clause: the ray leaves the
-// sphere's box within 1e-4 of its origin (it starts inside an overlapping sphere, just under its surface) and the reference
-// does not see the hit.  The far intersection t_far bounds the box's exit from below, so t_far comfortably above 1e-4 settles
-// it; otherwise the box test is evaluated exactly as the reference does (the leaf box is c -+ r, lbvh_builder.cu:33-41).
-MIRT_DEV bool sphere_leaf_box_admits(const float4 q, const f3& o, const f3& d, float tc, float t_far)
+// The reference's leaf box of a sphere (c -+ r, lbvh_builder.cu:33-41) against a ray, as hit_aabb_adapted evaluates it
+// (bvh_traversal.cu:11-44): entry and exit parameters.
+MIRT_DEV void sphere_leaf_box(const float4 q, const f3& o, const f3& inv, float& te, float& tx)
 {
-  if (t_far > 0.0001f + 1e-5f * (fabsf(tc) + fabsf(q.w))) return true;
-  const f3 inv = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
   const float ax = q.x - q.w, bx = q.x + q.w, ay = q.y - q.w, by = q.y + q.w, az = q.z - q.w, bz = q.z + q.w;
   const float xmin = (ax <= bx) ? ax : bx, xmax = (ax <= bx) ? bx : ax;
   const float ymin = (ay <= by) ? ay : by, ymax = (ay <= by) ? by : ay;
@@ -216,8 +211,21 @@ MIRT_DEV bool sphere_leaf_box_admits(const float4 q, const f3& o, const f3& d, f
   const float tx1 = (xmin - o.x) * inv.x, tx2 = (xmax - o.x) * inv.x;
   const float ty1 = (ymin - o.y) * inv.y, ty2 = (ymax - o.y) * inv.y;
   const float tz1 = (zmin - o.z) * inv.z, tz2 = (zmax - o.z) * inv.z;
-  const float te = fmaxf(fmaxf(fminf(tx1, tx2), fminf(ty1, ty2)), fminf(tz1, tz2));
-  const float tx = fminf(fminf(fmaxf(tx1, tx2), fmaxf(ty1, ty2)), fmaxf(tz1, tz2));
+  te = fmaxf(fmaxf(fminf(tx1, tx2), fminf(ty1, ty2)), fminf(tz1, tz2));
+  tx = fminf(fminf(fmaxf(tx1, tx2), fmaxf(ty1, ty2)), fmaxf(tz1, tz2));
+}
+
+// A sphere reached through quantised (larger) boxes skipped part of the box test its leaf gets in the reference's walk.  Of the
+// order-independent clauses of that test (bvh_traversal.cu:11-44) the one a hit sphere fails in exact arithmetic is
+// `t_exit > t_min`: the ray leaves the sphere's box within 1e-4 of its origin (it starts inside an overlapping sphere, just
+// under its surface) and the reference does not see the hit.  The far intersection t_far bounds the box's exit from below, so
+// t_far comfortably above 1e-4 settles it; otherwise the box test is evaluated exactly as the reference does.  (What rounding
+// can do to the other clauses is the business of hit_needs_literal_walk below.)
+MIRT_DEV bool sphere_leaf_box_admits(const float4 q, const f3& o, const f3& d, float tc, float t_far)
+{
+  if (t_far > 0.0001f + 1e-5f * (fabsf(tc) + fabsf(q.w))) return true;
+  float te, tx;
+  sphere_leaf_box(q, o, mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z), te, tx);
   return te < tx && tx > 0.0001f;
 }
 
@@ -354,6 +362,53 @@ MIRT_DEV void start_ray(const Args& a, Lane& S, Counters& cn)
 
 MIRT_DEV void set_ray(Lane& S, const RayS& r) { S.o = r.o; S.d = r.d; S.bounce = r.bounce; }
 
+// The walk of lane S ended with a sphere hit that is about to be shaded: would the reference's walk have found it?  Any order
+// other than the reference's, and any boxes larger than its own, rest on one property of its box test (bvh_traversal.cu:11-44):
+// a sphere that is hit passes the test of its leaf box and of every box above it, whatever the best distance so far -- the hit
+// lies inside them.  In float arithmetic that fails within a few ulp of t: a hit distance that rounds to just below the entry
+// distance of the sphere's own box (a ray that touches the sphere where the sphere touches its box, seen from so far away that
+// ulp(t) is the size of the gap).  The reference then sees the sphere or not depending on what it found before; a walk in
+// another order, or over larger boxes, can end with a hit the reference never tests.  So the hit a nearest-hit walk ends with
+// must be one the reference provably reaches: its exact leaf box passes the order-independent clauses and is entered before
+// the hit -- every box above contains the leaf box and the slab arithmetic is monotone in the box planes, so t_enter(above) <=
+// t_enter(leaf) < t <= the best distance at the time that box was tested.  Otherwise the ray is walked again exactly as the
+// reference does it (walk_literally below).  Two stages (hit_needs_literal_walk), at the start of the shade phase that consumes
+// the walk:
+// hit_at_risk -- the point o + T d lies inside the sphere's box by more than every rounding of the box test: with u = 2^-24,
+// per axis  T - t_enter >= ((r - |v|)(1 - 2.01u) - 2.1u(|c| + r + |o|)) / |d| - 2.01u T  for v = o + T d - c evaluated within
+// 3u(|o| + T + |c|), hence  r - |v| > 8u(|o| + |c| + r + T)  suffices, and |c| + r is at most the largest coordinate of the
+// scene box (`slack` = 2^-21 of it) -- says "provably reached" for all but a few hits per million; for the others the leaf
+// box test itself is evaluated.  Shadow rays need none of this: a ray to a sun is occluded iff any sphere is hit, in any order
+// (the reference culls by distance only once it has a hit); towards a point light the same holds unless an occluder's hit
+// distance and the light's agree to the ulp.
+// What stays an assumption is the mirror image: that no walk of the product CULLS a box over a sphere whose computed hit distance
+// lies below that box's entry distance and below the best distance of the moment, while the reference -- in its order -- gets
+// there first.  Over the quantised boxes that takes a disagreement of more than a grid step plus their 8-ulp margin; over the
+// exact boxes, near child first, one ulp.  traversal = 0 assumes nothing; the fuzzer compares the two.
+// Found by the mode fuzzer (tools/fuzz_modes.py seed 47, scene 795: one ray in 2.7e8; tests/golden/far_camera_tie.txt).
+MIRT_DEV bool hit_at_risk(const float4 q, const f3& o, const f3& d, float t, float slack)
+{
+  const float vx = __builtin_fmaf(t, d.x, o.x) - q.x, vy = __builtin_fmaf(t, d.y, o.y) - q.y, vz = __builtin_fmaf(t, d.z, o.z) - q.z;
+  const float m = fmaxf(fmaxf(fabsf(vx), fabsf(vy)), fabsf(vz));
+  const float margin = __builtin_fmaf(((fabsf(o.x) + fabsf(o.y)) + fabsf(o.z)) + t, 4.76837158203125e-07f, slack);
+  return !(q.w - m > margin);
+}
+
+// The vetting of a lane whose finished walk is about to be shaded (advance): true = walk the ray again.
+template <bool QN>
+MIRT_DEV bool hit_needs_literal_walk(const RenderArgs& a, const Lane& S)
+{
+  // (nothing to vet: no sphere hit, or the plane is nearer; the reference's own order over its own boxes; a ray that was already
+  // walked again; a shading node without a reflection ray -- nothing was traced for it, advance_core's no_ray)
+  if (S.refbest == REF_NONE || (S.refbest & REF_TRI) != 0u || !a.reach_check || (QN && S.qsx == 0u)) return false;
+  if ((S.plane_id >= 0 && !(S.tbest < S.tplane)) || (S.state == ST_BATCH && !S.has_reflect)) return false;
+  const float4 q = a.nodes[S.refbest & REF_OFFMASK];
+  if (!hit_at_risk(q, S.o, S.d, S.tbest, a.reach_slack)) return false;
+  float te, tx;
+  sphere_leaf_box(q, S.o, mk3(1.0f / S.d.x, 1.0f / S.d.y, 1.0f / S.d.z), te, tx);
+  return !(te < tx && tx > 0.0001f && te < S.tbest);
+}
+
 // A light the (rough) shading normal faces away from contributes colour * light * max(dot, 0) = 0 whether it is occluded or
 // not (draw.cu:353-357, 371-374), so its shadow ray is answered without a traversal: it still counts as a ray, and the light
 // is left "not occluded" (its term is then computed as usual and is 0).  Needs every colour of the scene to be finite
@@ -447,6 +502,63 @@ MIRT_DEV void batch_next(const Args& a, Lane& S, Counters& cn)
 MIRT_DEV float4* pending_entry(const RenderArgs& a, const long long gid, const int slot)
 {
   return reinterpret_cast<float4*>(a.pending) + ((size_t)gid * (size_t)a.pending_slots + (size_t)slot) * (PENDING_WORDS / 4);
+}
+
+// The ray of lane S again, exactly as the reference walks it (traverse_lbvh, bvh_traversal.cu:92-183: the exact 64-byte records
+// from node 0 at heap offset 0, left child first, nearest hit), in place and by this lane alone: the shade phase found that its
+// hit may be one the reference never tests (hit_at_risk above; a few rays per 10^7).  The lane's traversal
+// stack is empty at this point: the walk keeps its own in the lane's column of the spill area.
+template <bool COUNT, bool NOTRI>
+MIRT_DEV void walk_literally(const RenderArgs& a, Lane& S, Counters& cn, const long long gid, const long long gthreads)
+{
+  uint32_t* const stack = a.stack_spill;
+  const f3 inv = mk3(1.0f / S.d.x, 1.0f / S.d.y, 1.0f / S.d.z);
+  const float tmin = 0.0001f;
+  float tbest = INFINITY;
+  uint32_t refbest = REF_NONE, cur = 0u;
+  int sp = 0;
+  for (;;) {
+    const float4* rec = a.nodes + (cur & REF_OFFMASK);
+    bool pop;
+    if (cur & REF_LEAF) {
+      float t = 0.0f, tc, t_far;
+      bool hit;
+      if (!NOTRI && (cur & REF_TRI)) { if (COUNT) cn.tri_tests++; hit = triangle_hit(rec[0], rec[1], rec[2], S.o, S.d, t); }
+      else { if (COUNT) cn.sphere_tests++; hit = sphere_hit(rec[0], S.o, S.d, t, tc, t_far); }
+      if (closer_hit(hit, t, tbest, cur & REF_OFFMASK, refbest)) { tbest = t; refbest = cur; }
+      pop = true;
+    } else {
+      if (COUNT) cn.internal_visits++;
+      // hit_aabb_adapted on the left child, then on the right one (one box at a time: this code runs a few times per frame and
+      // must not cost the shade phase around it a register); the record: left x, y | left z, right x | right y, z | references
+      bool hc[2];
+#pragma unroll 1
+      for (int c = 0; c < 2; ++c) {
+        const float2* b = reinterpret_cast<const float2*>(rec) + 3 * c;
+        const float2 bx = b[0], by = b[1], bz = b[2];
+        const float tx1 = (bx.x - S.o.x) * inv.x, tx2 = (bx.y - S.o.x) * inv.x;
+        const float ty1 = (by.x - S.o.y) * inv.y, ty2 = (by.y - S.o.y) * inv.y;
+        const float tz1 = (bz.x - S.o.z) * inv.z, tz2 = (bz.y - S.o.z) * inv.z;
+        const float te = fmaxf(fmaxf(fminf(tx1, tx2), fminf(ty1, ty2)), fminf(tz1, tz2));
+        const float tx = fminf(fminf(fmaxf(tx1, tx2), fmaxf(ty1, ty2)), fmaxf(tz1, tz2));
+        hc[c] = te < tx && te < tbest && tx > tmin;
+      }
+      const uint2 ch = *reinterpret_cast<const uint2*>(rec + 3);
+      if (hc[0] && hc[1]) {
+        stack[(size_t)sp * gthreads + gid] = ch.y;
+        ++sp;
+        if (COUNT) cn.max_stack = max(cn.max_stack, (uint32_t)sp);
+      }
+      cur = hc[0] ? ch.x : ch.y;
+      pop = !(hc[0] || hc[1]);
+    }
+    if (pop) {
+      if (sp == 0) break;
+      --sp;
+      cur = stack[(size_t)sp * gthreads + gid];
+    }
+  }
+  S.tbest = tbest; S.refbest = refbest;
 }
 
 // Consume the finished trace of lane S and run its shading state machine until it either has the next ray(s) or the

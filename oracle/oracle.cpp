@@ -117,6 +117,14 @@ typedef struct {
  * the same order, which is all the argument under ORC_FLAG_QNODES needs.  Half as many dependent steps per ray.  Needs QNODES;
  * the descent order is the reference's at every node (no near-child-first, not even between sphere-only subtrees). */
 #define ORC_FLAG_WIDE          64u
+/* Any walk that is not the reference's own (another order, larger boxes) vets the sphere hit a nearest-hit query ends with
+ * before it is shaded (the product: hit_needs_literal_walk, shade_common.h): a sphere's hit distance can round to just below the
+ * entry distance of its own leaf box -- a ray that touches the sphere where the sphere touches its box, from far away -- and
+ * then the reference tests that sphere or not depending on what it found before, while another walk may end with it.  If the
+ * exact leaf box passes its order-independent clauses and is entered before the hit, the reference provably reaches the leaf
+ * (the argument under ORC_FLAG_QNODES); otherwise the ray is walked again by traverse(), literally.  Shadow queries are not
+ * vetted (the product's argument: occluded iff anything is hit, in any order).  Not set for the wavefront path. */
+#define ORC_FLAG_REACH         128u
 #define ORC_FLAG_ORDERED       4u
 #define ORC_FLAG_ORDERED_ALL   8u   /* near child first at every node (triangle silhouettes may differ from the reference order) */
 
@@ -556,10 +564,12 @@ static inline Mat mat_from(const OMat& o) { Mat m; m.color = c3(o.color); m.shin
 struct Obj {
   bool isHit; float distance; V3 i_point, normal; Mat mat;
   uint32_t kind, id; /* bookkeeping only: 1 sphere, 2 triangle, 3 plane */
+  uint32_t leaf;     /* bookkeeping: sorted position of the primitive (its leaf is node N - 1 + leaf) */
+  bool literal;      /* bookkeeping: the result of a second, literal walk (ORC_FLAG_QNODES / ORC_FLAG_REACH) */
 };
-static inline Obj obj_none() { Obj o; o.isHit = false; o.distance = -1.0f; o.i_point = mk(0, 0, 0); o.normal = mk(0, 0, 0); o.mat = mat_default(); o.kind = 0; o.id = 0; return o; }
+static inline Obj obj_none() { Obj o; o.isHit = false; o.distance = -1.0f; o.i_point = mk(0, 0, 0); o.normal = mk(0, 0, 0); o.mat = mat_default(); o.kind = 0; o.id = 0; o.leaf = 0; o.literal = false; return o; }
 static inline Obj obj_hit(float t, const V3& p, const V3& n, const Mat& m, uint32_t kind, uint32_t id)
-{ Obj o; o.isHit = true; o.distance = t; o.i_point = p; o.normal = n; o.mat = m; o.kind = kind; o.id = id; return o; }
+{ Obj o; o.isHit = true; o.distance = t; o.i_point = p; o.normal = n; o.mat = m; o.kind = kind; o.id = id; o.leaf = 0; o.literal = false; return o; }
 
 struct Ctx {
   const Scene* sc;
@@ -778,9 +788,9 @@ static Obj traverse_ordered(Ctx& cx, const Ray& ray, float initial_t_max, bool e
         if (qn && ref.type != 0) {      /* would the reference's walk have reached this triangle? (ORC_FLAG_QNODES above) */
           float te;
           const bool box_ok = hit_aabb_t(node, ray.eye, inv, tmin, INFINITY, &te);      /* t_enter < t_exit && t_exit > t_min */
-          if (!(box_ok && te < h.distance)) { cx.st.qn_retraces++; return traverse_ordered(cx, ray, initial_t_max, early, stop_below, false); }
+          if (!(box_ok && te < h.distance)) { cx.st.qn_retraces++; Obj lit = traverse(cx, ray, initial_t_max, early, stop_below); lit.literal = true; return lit; }
         }
-        tmax = h.distance; best = h; best_leaf = k; have = true;
+        tmax = h.distance; best = h; best.leaf = k; best_leaf = k; have = true;
         if (early && best.distance < stop_below) return best;
       }
       if (sp == 0) break;
@@ -848,9 +858,9 @@ static Obj traverse_wide(Ctx& cx, const Ray& ray, float initial_t_max, bool earl
         if (ref.type != 0) {
           float te;
           const bool box_ok = hit_aabb_t(node, ray.eye, inv, tmin, INFINITY, &te);
-          if (!(box_ok && te < h.distance)) { cx.st.qn_retraces++; return traverse_ordered(cx, ray, initial_t_max, early, stop_below, false); }
+          if (!(box_ok && te < h.distance)) { cx.st.qn_retraces++; Obj lit = traverse(cx, ray, initial_t_max, early, stop_below); lit.literal = true; return lit; }
         }
-        tmax = h.distance; best = h; best_leaf = k; have = true;
+        tmax = h.distance; best = h; best.leaf = k; best_leaf = k; have = true;
         if (early && best.distance < stop_below) return best;
       }
       if (sp == 0) break;
@@ -923,6 +933,15 @@ static Obj hit_nearest(Ctx& cx, const Ray& ray, bool count_mat = true)
   cx.st.rays++;
   Obj b = traverse_any(cx, ray, INFINITY, false, -1.0f);
   Obj p = check_plane(cx, ray);
+  const uint32_t N = (uint32_t)cx.sc->refs.size();
+  /* ORC_FLAG_REACH: where the product reads the sphere's record to shade it, i.e. when the BVH hit is the nearer one */
+  if ((cx.flags & ORC_FLAG_REACH) && count_mat /* (not a shadow query) */ && b.isHit && b.kind == 1 && !b.literal && N > 1 &&
+      (!p.isHit || b.distance < p.distance) && (cx.flags & (ORC_FLAG_ORDERED | ORC_FLAG_ORDERED_ALL | ORC_FLAG_QNODES))) {
+    const V3 inv = mk(1.0f / ray.dir.x, 1.0f / ray.dir.y, 1.0f / ray.dir.z);
+    float te;
+    const bool box_ok = hit_aabb_t(cx.sc->nodes[N - 1 + b.leaf], ray.eye, inv, 0.0001f, INFINITY, &te);
+    if (!(box_ok && te < b.distance)) { cx.st.qn_retraces++; b = traverse(cx, ray, INFINITY, false, -1.0f); }
+  }
   Obj r;
   if (b.isHit && p.isHit) r = (b.distance < p.distance) ? b : p;
   else if (b.isHit) r = b;

@@ -17,7 +17,8 @@ FLAG_SKIP_UNLIT = 16    # shadow rays towards lights the shading normal faces aw
 # where pixels cannot change, by default -- the oracle mirrors each so that the visit counters can be compared with ==
 FLAG_QNODES = 32        # quantised node records (single-kernel path, traversal >= 1; triangle hits outside their exact leaf box re-walk the exact boxes)
 FLAG_WIDE = 64          # wide walk over the quantised records: grandchildren tested per step, reference order (scenes with triangles)
-PRODUCT_ALWAYS = FLAG_ANYHIT_SHADOW | FLAG_SKIP_UNLIT      # (the defaults of the scene options shadow_anyhit / skip_unlit)
+FLAG_REACH = 128        # the sphere hit a nearest-hit query ends with is vetted; a ray whose hit the reference may not reach is walked literally (single-kernel path)
+PRODUCT_ALWAYS = FLAG_ANYHIT_SHADOW | FLAG_SKIP_UNLIT | FLAG_REACH      # (the defaults of the scene options shadow_anyhit / skip_unlit; the single-kernel path)
 PRODUCT_FLAGS = PRODUCT_ALWAYS | FLAG_ORDERED | FLAG_QNODES   # default options, single-kernel path, a scene WITHOUT triangles
 PRODUCT_FLAGS_TRI = PRODUCT_FLAGS | FLAG_WIDE                 # ... a scene with triangles and 65536 primitives or more (or qnodes = 2)
 PRODUCT_FLAGS_SMALL_TRI = PRODUCT_ALWAYS | FLAG_ORDERED       # ... a smaller scene with triangles: the exact records
@@ -32,6 +33,8 @@ def product_flags(scene_has_triangles, traversal=1, wavefront=False, qnodes=1, s
         f |= FLAG_ANYHIT_SHADOW
     if skip_unlit:
         f |= FLAG_SKIP_UNLIT
+    if not wavefront:
+        f |= FLAG_REACH
     if qnodes and not wavefront:
         if not scene_has_triangles and traversal >= 1:
             f |= FLAG_QNODES

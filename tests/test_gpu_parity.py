@@ -346,6 +346,44 @@ def test_default_mode_gives_the_bytes_of_the_reference_walk_mode(name, gpu_scene
     assert sa["rays"] == sb["rays"] and sa["internal_visits"] < 0.9 * sb["internal_visits"]
 
 
+@pytest.mark.parametrize("qnodes", [1, 0])
+def test_a_hit_the_reference_never_tests_sends_the_ray_over_its_literal_walk(qnodes):
+    """tests/golden/far_camera_tie.txt (three spheres of a fuzz scene, tools/fuzz_modes.py seed 47 scene 795; the camera 4 000
+    units away): the primary ray of pixel (50, 97) touches two spheres within one ulp of t, and the nearer hit rounds to just
+    below the entry distance of its own leaf box -- the reference, having met the other sphere first, never tests it; a walk
+    over the larger quantised boxes does.  The shade phase vets the hit (hit_needs_literal_walk) and walks the ray again literally:
+    every counter equals the oracle's mirror (one re-walk), and the frame -- bytes, float image, ray count -- is the
+    reference-walk mode's.  Without the vetting the frame traces one ray more (the oracle restates that too)."""
+    import cuda_ray_tracer_amd as m
+    import pyscene
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "far_camera_tie.txt")
+    stl = m.parseInput(path)
+    raw = m.initRawConfigFromStl(stl, 0)
+    m.build_lbvh_karas(raw)
+    osc = ol.OracleScene(pyscene.parse_lines(open(path).read().split("\n")), bounds_mode=0)
+    w, h, spp = 192, 108, 0
+    try:
+        with options(raw, qnodes=qnodes):
+            a8, af = gpu_render(raw, w, h, spp, counters=True)
+            sa = raw.stats()
+        with options(raw, **REFERENCE_WALK):
+            b8, bf = gpu_render(raw, w, h, spp, counters=True)
+            sb = raw.stats()
+        flags = ol.product_flags(False, qnodes=qnodes)
+        ref = osc.render(w, h, spp, flags=flags, nthreads=8)
+        plain = osc.render(w, h, spp, flags=0, nthreads=8)
+        unvetted = osc.render(w, h, spp, flags=flags & ~ol.FLAG_REACH, nthreads=8)
+    finally:
+        raw.close()
+    for k in COUNTER_KEYS:
+        assert sa[k] == ref["stats"][k], (k, sa[k], ref["stats"][k])
+        assert sb[k] == plain["stats"][k], (k, sb[k], plain["stats"][k])
+    assert np.array_equal(a8, b8) and np.array_equal(af.view(np.uint32), bf.view(np.uint32))
+    assert sa["rays"] == sb["rays"] == plain["stats"]["rays"]
+    if qnodes:
+        assert ref["stats"]["qn_retraces"] == 1 and unvetted["stats"]["rays"] == plain["stats"]["rays"] + 1
+
+
 @pytest.mark.parametrize("name", ["tenthousand", "spiral", "redchair", "tri"])
 def test_default_traversal_gives_the_bytes_of_the_reference_order(name, gpu_scenes):
     """The ordered traversal changes which nodes are visited, never the closest hit: the whole 1920x1080 x 16 spp frame
@@ -359,7 +397,8 @@ def test_default_traversal_gives_the_bytes_of_the_reference_order(name, gpu_scen
         b8, bf = gpu_render(raw, w, h, spp, counters=True)
         sb = raw.stats()
     assert np.array_equal(a8, b8) and np.array_equal(af.view(np.uint32), bf.view(np.uint32))
-    assert sa["rays"] == sb["rays"] and sa["internal_visits"] <= sb["internal_visits"]
+    # (a handful of rays per frame are walked twice: hit_needs_literal_walk)
+    assert sa["rays"] == sb["rays"] and sa["internal_visits"] <= sb["internal_visits"] * 1.00001
     if name in ("tenthousand", "spiral"):
         assert sa["internal_visits"] < 0.85 * sb["internal_visits"]
 

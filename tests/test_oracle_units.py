@@ -230,6 +230,30 @@ def test_quantised_and_wide_walks_give_the_image_of_the_reference_walk(name, w, 
         assert q["stats"]["qn_retraces"] == 0
 
 
+def test_a_hit_below_the_entry_distance_of_its_own_box_is_vetted():
+    """tests/golden/far_camera_tie.txt, pixel (50, 97) of a 192x108 frame: two overlapping spheres 4 256 units from the camera
+    are hit within one ulp of t (4256.1167 and 4256.11719).  The reference's walk meets the farther one first and then culls
+    the leaf box of the nearer one (its entry distance rounds above the best distance), so it shades the farther sphere; a walk
+    over the quantised boxes reaches the nearer one, shades it, and traces one ray more (found by tools/fuzz_modes.py: seed 47,
+    scene 795; the pixel is black either way).  With ORC_FLAG_REACH (the product's hit_needs_literal_walk) the hit is recognised
+    as one the reference may not reach and the ray is walked again literally: counters and image of the plain restatement."""
+    import os
+    import pyscene
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "far_camera_tie.txt")
+    o = ol.OracleScene(pyscene.parse_lines(open(path).read().split("\n")), bounds_mode=0)
+    tile = (50, 97, 1, 1)
+    plain = o.render(192, 108, 0, tile=tile, flags=0)
+    unvetted = o.render(192, 108, 0, tile=tile, flags=ol.PRODUCT_FLAGS & ~ol.FLAG_REACH)
+    vetted = o.render(192, 108, 0, tile=tile, flags=ol.PRODUCT_FLAGS)
+    assert unvetted["stats"]["rays"] == plain["stats"]["rays"] + 1 and unvetted["stats"]["qn_retraces"] == 0
+    assert vetted["stats"]["rays"] == plain["stats"]["rays"] and vetted["stats"]["qn_retraces"] == 1
+    whole = [o.render(192, 108, 0, flags=f, nthreads=8) for f in (0, ol.PRODUCT_FLAGS, ol.PRODUCT_FLAGS_TRI, ol.PRODUCT_FLAGS_SMALL_TRI)]
+    for m in whole[1:]:
+        assert np.array_equal(whole[0]["f32"].view(np.uint32), m["f32"].view(np.uint32))
+        for k in ("rays", "shadow_rays", "mat_fetches"):
+            assert whole[0]["stats"][k] == m["stats"][k], k
+
+
 def test_a_zero_direction_component_does_not_switch_an_axis_off_in_the_quantised_walk(oracle_scenes):
     """redchair.txt's `sun 0 1 2` has a zero x component.  Rounds 1-2 ignored such an axis in the quantised box test (a superset,
     so still exact) and every shadow ray of that sun then tested two axes only; the reciprocal is clamped instead.  The quantised

@@ -101,6 +101,8 @@ def main(argv=None):
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--out", default="gpurun_out", help="where the scene text of a mismatch is written")
     ap.add_argument("--triangles", type=float, default=0.0, help="triangles per sphere added to every scene (mixed scenes: float node records)")
+    ap.add_argument("--qnodes", type=int, default=1, help="scene option qnodes of the first render (2: quantised records on every scene, i.e. the wide walk on the mixed ones)")
+    ap.add_argument("--reference-walk", action="store_true", help="compare with {traversal 0, shadow_anyhit 0, skip_unlit 0, qnodes 0}: the reference's walk ray for ray")
     args = ap.parse_args(argv)
     rng = np.random.default_rng(args.seed)
     bad = 0
@@ -111,12 +113,17 @@ def main(argv=None):
         stl = m.parseText(text)
         raw = m.initRawConfigFromStl(stl, 0)
         m.build_lbvh_karas(raw)
+        raw.set_option("qnodes", args.qnodes)
         a8, af, sa = render(raw, w, h, spp)
+        a8b, afb, _ = render(raw, w, h, spp)          # the same options again: now in the measured hand-out order
         raw.set_option("traversal", 0)
+        if args.reference_walk:
+            for k in ("shadow_anyhit", "skip_unlit", "qnodes"):
+                raw.set_option(k, 0)
         b8, bf, sb = render(raw, w, h, spp)
         raw.close()
         visits[0] += sa["internal_visits"]; visits[1] += sb["internal_visits"]
-        ok = np.array_equal(a8, b8) and np.array_equal(af, bf) and sa["rays"] == sb["rays"]
+        ok = np.array_equal(a8, b8) and np.array_equal(af, bf) and sa["rays"] == sb["rays"] and np.array_equal(a8, a8b) and np.array_equal(af, afb)
         if not ok:
             bad += 1
             nd = int((a8.reshape(-1, 4) != b8.reshape(-1, 4)).any(axis=1).sum())
