@@ -126,7 +126,7 @@ def cpu_baseline(scene_file, width, height, spp, step):
     dt = time.perf_counter() - t0
     o.close()
     return {"value": st["rays"] / dt / 1e6, "unit": "Mrays/s", "cores": 1, "kind": "port",
-            "sample": f"every {step}th pixel in x and y of the {width}x{height} frame at {spp} spp "
+            "sample": f"every pixel whose x and y are multiples of {step} of the {width}x{height} frame at {spp} spp "
                       f"({st['samples']} samples, {st['rays']} rays, {dt:.1f} s; the reference's own traversal: left-first order, "
                       f"full nearest-hit shadow rays to every light)"}
 
