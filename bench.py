@@ -197,6 +197,8 @@ def main():
     ap.add_argument("--config5-spp", type=int, default=256, help="samples per pixel of the synthetic 2 M-primitive configuration (BASELINE: 256)")
     args = ap.parse_args()
 
+    # (the pool's host driver only supports dmabuf IPC: without this RCCL fails with `hipIpcGetMemHandle: invalid argument`)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     import torch
     import torch.distributed as dist
     import cuda_ray_tracer_amd as m
