@@ -430,6 +430,17 @@ def test_random_sphere_scenes_default_mode_equals_reference_order(tmp_path):
     assert fuzz_modes.main(["--scenes", "60", "--seed", "11", "--out", str(tmp_path)]) == 0
 
 
+@pytest.mark.parametrize("extra", [[], ["--triangles", "1.0", "--qnodes", "2"]], ids=["spheres", "mixed-wide"])
+def test_far_camera_scenes_default_mode_equals_the_reference_walk_mode(extra, tmp_path):
+    """The regime of tests/golden/far_camera_tie.txt at random (fuzz_modes.py --far: cameras 10^3 .. 10^5 scene sizes away, many
+    large overlapping spheres; the oracle counts five literal re-walks per scene there on average): 100 scenes per kind, the
+    default mode -- rendered twice, the second time in the measured hand-out order -- against the reference-walk mode
+    (traversal 0, shadow_anyhit 0, skip_unlit 0, qnodes 0): bytes, float image and ray count."""
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import fuzz_modes
+    assert fuzz_modes.main(["--scenes", "100", "--seed", "71", "--far", "--reference-walk", "--out", str(tmp_path)] + extra) == 0
+
+
 def test_shipped_tree_mode_reproduces_the_survey_golden_image(gpu_scenes, oracle_scenes):
     """Build option bounds_as_shipped: the reference as shipped never stores its scene bounds (parse.cpp:28), so every
     Morton code is 0.  With it, and the reference's traversal order, the HIP path itself reproduces the RNG-free known
