@@ -735,7 +735,12 @@ static int render_impl(MirtScene* sc, const MirtRenderParams* p, void* d_rgba8, 
   a.qparams = qn ? sc->qparams : nullptr;
   a.tri_boxes = sc->tri_boxes;
   a.prim_base16 = sc->prim_base / 16u;
-  a.swap_mask = opt.traversal == 1 ? NODE_SWAP_PURE : (opt.traversal == 2 ? NODE_SWAP_ANY : 0u);
+  // traversal = 1: near child first on the quantised records of a sphere-only scene, nowhere else.  Over the exact boxes the
+  // reordered walk can cull a box over a sphere whose hit distance rounds below that box's entry distance (one ulp is enough; the
+  // reference, in its order, gets there first): 13 of 4 000 far-camera fuzz scenes differed by a pixel or a ray.  The quantised
+  // boxes are rounded outwards by more than that rounding as long as the grid resolves it (near_first_ok) -- no differing byte
+  // in 10 000 sphere scenes, 3 000 of them far-camera ones.  Everything else walks in the reference's order.
+  a.swap_mask = opt.traversal == 1 ? ((qn && notri && sc->near_first_ok) ? NODE_SWAP_PURE : 0u) : (opt.traversal == 2 ? NODE_SWAP_ANY : 0u);
   a.skip_unlit = (opt.skip_unlit != 0 && sc->colors_finite && sc->d.num_suns + sc->d.num_bulbs <= 32) ? 1 : 0;
   a.shadow_anyhit = opt.shadow_anyhit != 0 ? 1 : 0;
   a.planes = sc->planes; a.num_planes = sc->d.num_planes;

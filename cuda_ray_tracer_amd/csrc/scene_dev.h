@@ -246,6 +246,7 @@ struct MirtScene {
   bool built = false;
   float build_ms = 0.0f;
   float coord_max = 0.0f;               // largest |coordinate| of the scene box (set by the build)
+  bool near_first_ok = false;           // the quantised grid is fine enough for near-child-first descent to be exact (set by the build)
   // render workspaces: MIRT_MAX_FRAMES contexts so that several frames can be in flight on different streams (the next frame's blocks fill the
   // CUs the draining frame frees); a context is reused only after its previous frame has finished
   mirt::RenderCtx ctx[mirt::MIRT_MAX_FRAMES];

@@ -95,9 +95,11 @@ void mirt_scene_destroy(MirtScene* sc);
  *                         (parse.cpp:28), every Morton code 0
  *   render:
  *     "traversal"         MIRT_TRAVERSAL_*: 0 the reference's left-first descent (bvh_traversal.cu:149-157); 1 (default)
- *                         near-child-first at nodes whose subtrees hold spheres only -- same pixels, fewer visits;
- *                         2 near-child-first everywhere (a triangle-silhouette sample may differ where the
- *                         reference's own result depends on its visiting order)
+ *                         near-child-first on the quantised records of a sphere-only scene (see qnodes) -- same pixels, fewer
+ *                         visits; the reference's order wherever the exact records are walked (scenes with triangles below
+ *                         65536 primitives, qnodes 0, wavefront) and over the wide records; 2 near-child-first everywhere (a
+ *                         sample may differ where the reference's own result depends on its visiting order: triangle
+ *                         silhouettes, sphere hits within an ulp of their box from a far camera)
  *     "qnodes"            0/1/2 (default 1): quantised node records in the single-kernel path.  1: sphere-only scenes walk 32-byte
  *                         records (two memory requests per node visit instead of four; traversal >= 1); scenes with triangles of
  *                         65536 primitives or more walk the wide records (the boxes of a node's four grandchildren per 64-byte

@@ -897,7 +897,8 @@ static inline Obj traverse_any(Ctx& cx, const Ray& ray, float initial_t_max, boo
 {
   if (!cx.sc->nodes.empty()) cx.st.traversals++;      /* rays that enter the BVH walk (MirtStats.rays_traversed) */
   if ((cx.flags & ORC_FLAG_WIDE) && (cx.flags & ORC_FLAG_QNODES) && cx.sc->refs.size() > 1) return traverse_wide(cx, ray, initial_t_max, early, stop_below);
-  if (cx.flags & (ORC_FLAG_ORDERED | ORC_FLAG_ORDERED_ALL)) return traverse_ordered(cx, ray, initial_t_max, early, stop_below);
+  /* (QNODES without an ORDERED flag: the quantised boxes in the reference's order -- a scene whose grid is too coarse for near child first) */
+  if (cx.flags & (ORC_FLAG_ORDERED | ORC_FLAG_ORDERED_ALL | ORC_FLAG_QNODES)) return traverse_ordered(cx, ray, initial_t_max, early, stop_below);
   return traverse(cx, ray, initial_t_max, early, stop_below);
 }
 

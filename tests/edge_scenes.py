@@ -141,6 +141,20 @@ def far_camera(n=400):
     return "".join(out)
 
 
+def far_from_origin(n=300, offset=1000.0):
+    """A unit-sized cluster of spheres 1 000 units from the world origin: ulp(coordinate) = 6e-5 is two steps of the quantised
+    grid (2 / 65535), so the outward rounding of the quantised boxes no longer covers the rounding of a sphere's own box planes
+    -- the build clears `near_first_ok` and the quantised records are walked in the reference's order (lbvh_build.hip)."""
+    rng = np.random.default_rng(12)
+    out = [HEADER, "bounces 3\n", "eye %.1f 0.3 4\n" % offset, "forward 0 0 -1\n", "color 1 1 1\n", "sun 1 1 1\n", "sun -1 2 0.5\n",
+           "color 0.6 0.6 0.6\n", "shininess 0.3\n", "plane 0 1 0 1\n", "shininess 0.5\n"]
+    for _ in range(n):
+        c = rng.uniform(-1, 1, 3)
+        out.append("color %.3f %.3f %.3f\n" % tuple(rng.uniform(0.2, 1, 3)))
+        out.append("sphere %.4f %.4f %.4f %.4f\n" % (offset + c[0], c[1], c[2], rng.uniform(0.03, 0.12)))
+    return "".join(out)
+
+
 def axis_parallel_rays(n=6):
     """An n x n x n lattice of spheres around the camera, which sits inside the scene's bounds and looks straight down -z: at
     spp 0 and an even frame size the central column and row of pixels have direction components that are exactly 0 (reciprocal

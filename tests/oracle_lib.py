@@ -21,25 +21,28 @@ FLAG_REACH = 128        # the sphere hit a nearest-hit query ends with is vetted
 PRODUCT_ALWAYS = FLAG_ANYHIT_SHADOW | FLAG_SKIP_UNLIT | FLAG_REACH      # (the defaults of the scene options shadow_anyhit / skip_unlit; the single-kernel path)
 PRODUCT_FLAGS = PRODUCT_ALWAYS | FLAG_ORDERED | FLAG_QNODES   # default options, single-kernel path, a scene WITHOUT triangles
 PRODUCT_FLAGS_TRI = PRODUCT_FLAGS | FLAG_WIDE                 # ... a scene with triangles and 65536 primitives or more (or qnodes = 2)
-PRODUCT_FLAGS_SMALL_TRI = PRODUCT_ALWAYS | FLAG_ORDERED       # ... a smaller scene with triangles: the exact records
+PRODUCT_FLAGS_SMALL_TRI = PRODUCT_ALWAYS                      # ... a smaller scene with triangles: the exact records, the reference's order
 REFERENCE_WALK = 0      # {traversal: 0, shadow_anyhit: 0, skip_unlit: 0, qnodes: 0}: draw.cu:292-377 + bvh_traversal.cu:92-183 verbatim
 
 
-def product_flags(scene_has_triangles, traversal=1, wavefront=False, qnodes=1, shadow_anyhit=True, skip_unlit=True, nprims=0):
+def product_flags(scene_has_triangles, traversal=1, wavefront=False, qnodes=1, shadow_anyhit=True, skip_unlit=True, nprims=0, near_first_ok=True):
     """The oracle flags that mirror what libmirt does for an option set (for counters to compare with ==).  qnodes: the scene
-    option (0 never, 1 sphere-only scenes and scenes with triangles of 65536 primitives or more, 2 every scene)."""
-    f = {0: 0, 1: FLAG_ORDERED, 2: FLAG_ORDERED_ALL}[traversal]
+    option (0 never, 1 sphere-only scenes and scenes with triangles of 65536 primitives or more, 2 every scene).  traversal = 1
+    reorders only the walk over the quantised records of a sphere-only scene -- and only if the scene's grid resolves the rounding
+    of its coordinates (near_first_ok: OracleScene.near_first_ok()); everything else keeps the reference's order."""
+    quantised = bool(qnodes) and not wavefront and not scene_has_triangles and traversal >= 1
+    wide = bool(qnodes) and not wavefront and scene_has_triangles and traversal == 1 and (qnodes >= 2 or nprims >= 65536)
+    f = {0: 0, 1: FLAG_ORDERED if ((quantised and near_first_ok) or wide) else 0, 2: FLAG_ORDERED_ALL}[traversal]
     if shadow_anyhit:
         f |= FLAG_ANYHIT_SHADOW
     if skip_unlit:
         f |= FLAG_SKIP_UNLIT
     if not wavefront:
         f |= FLAG_REACH
-    if qnodes and not wavefront:
-        if not scene_has_triangles and traversal >= 1:
-            f |= FLAG_QNODES
-        elif scene_has_triangles and traversal == 1 and (qnodes >= 2 or nprims >= 65536):
-            f |= FLAG_QNODES | FLAG_WIDE
+    if quantised:
+        f |= FLAG_QNODES
+    elif wide:
+        f |= FLAG_QNODES | FLAG_WIDE
     return f
 
 
@@ -179,6 +182,12 @@ class OracleScene:
         out = np.zeros(self.n, dtype=[("type", "<u4"), ("id", "<u4")])
         lib().orc_get_refs(self.h, out.ctypes.data)
         return out
+
+    def near_first_ok(self):
+        """lbvh_build.hip: every axis of the scene box has its coordinates below 128 extents (float arithmetic as there)."""
+        mn, mx = self.bounds()
+        ext = (mx - mn).astype(np.float32)
+        return bool(np.all(np.maximum(np.abs(mn), np.abs(mx)) <= np.float32(128.0) * ext))
 
     def bounds(self):
         mn = np.zeros(3, np.float32)

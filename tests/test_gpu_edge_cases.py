@@ -28,7 +28,8 @@ def run_case(text, w, h, spp, **options):
     tree = raw.tree() if stl.num_prims > 0 else None
     raw.close()
     o = ol.OracleScene(pyscene.parse_lines(text.split("\n")), bounds_mode=0)
-    ref = o.render(w, h, spp, flags=ol.product_flags(stl.num_triangles > 0, qnodes=options.get("qnodes", 1), nprims=stl.num_prims), nthreads=8)
+    ref = o.render(w, h, spp, flags=ol.product_flags(stl.num_triangles > 0, traversal=options.get("traversal", 1), qnodes=options.get("qnodes", 1),
+                                                      nprims=stl.num_prims, near_first_ok=o.near_first_ok()), nthreads=8)
     if tree is not None:
         on = o.nodes()
         for f in ("left", "right"):
@@ -68,12 +69,27 @@ def test_stack_spill_path():
 
 def test_quantised_nodes_are_conservative_for_far_ray_origins():
     """Sphere-only scene, camera 30 000 scene sizes away: the quantised records give the bytes of the 64-byte float records
-    (and of the oracle), with the oracle's visit counters."""
+    walked in the reference's order (and of the oracle), with the oracle's visit counters; they are larger boxes -- more visits
+    than the exact boxes in the same near-first order (traversal = 2 on the exact records), fewer than the reference's order."""
     text = edge_scenes.far_camera()
-    st_q, img_q = run_case(text, 96, 72, 4)                       # default: quantised nodes
-    st_f, img_f = run_case(text, 96, 72, 4, qnodes=0)
-    assert np.array_equal(img_q, img_f) and img_q[..., 3].max() == 255
-    assert st_q["rays"] == st_f["rays"] and st_q["internal_visits"] >= st_f["internal_visits"]
+    st_q, img_q = run_case(text, 96, 72, 4)                       # default: quantised nodes, near child first
+    st_l, img_l = run_case(text, 96, 72, 4, qnodes=0)             # exact records: the reference's order
+    st_f, img_f = run_case(text, 96, 72, 4, qnodes=0, traversal=2)
+    assert np.array_equal(img_q, img_l) and img_q[..., 3].max() == 255
+    assert st_q["rays"] == st_l["rays"] == st_f["rays"] and st_f["internal_visits"] <= st_q["internal_visits"] < st_l["internal_visits"]
+
+
+def test_a_scene_far_from_the_origin_keeps_the_reference_order_on_the_quantised_records():
+    """edge_scenes.far_from_origin: coordinates 450 times the scene's extent -- the quantised grid is coarser than the rounding
+    of the primitives' own box planes, so near child first is not taken (near_first_ok, lbvh_build.hip): the quantised records in
+    the reference's order, counters equal to the oracle's mirror of exactly that, bytes and ray count of the exact records."""
+    text = edge_scenes.far_from_origin()
+    o = ol.OracleScene(pyscene.parse_lines(text.split("\n")), bounds_mode=0)
+    assert not o.near_first_ok()
+    o.close()
+    st_q, img_q = run_case(text, 96, 72, 4)
+    st_l, img_l = run_case(text, 96, 72, 4, qnodes=0)
+    assert np.array_equal(img_q, img_l) and st_q["rays"] == st_l["rays"] and st_q["internal_visits"] >= st_l["internal_visits"]
 
 
 @pytest.mark.parametrize("name", ["fisheye", "single_triangle", "glass_gi_dof"])

@@ -286,7 +286,7 @@ def test_a_zero_direction_component_does_not_switch_an_axis_off_in_the_quantised
     so still exact) and every shadow ray of that sun then tested two axes only; the reciprocal is clamped instead.  The quantised
     walk must stay within a few per cent of the exact boxes' node visits."""
     o = oracle_scenes("redchair")
-    exact = o.render(96, 54, 4, flags=ol.PRODUCT_FLAGS_SMALL_TRI, nthreads=8)["stats"]
+    exact = o.render(96, 54, 4, flags=ol.PRODUCT_ALWAYS | ol.FLAG_ORDERED, nthreads=8)["stats"]
     quant = o.render(96, 54, 4, flags=ol.PRODUCT_FLAGS, nthreads=8)["stats"]
     assert exact["internal_visits"] <= quant["internal_visits"] < 1.08 * exact["internal_visits"]
 
