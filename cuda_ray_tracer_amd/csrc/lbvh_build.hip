@@ -645,19 +645,20 @@ int build_lbvh(MirtScene* sc, hipStream_t stream)
   MIRT_HIP(hipStreamSynchronize(stream));   // lbvh_builder.cu:475
   MIRT_HIP(hipEventElapsedTime(&sc->build_ms, sc->ev0, sc->ev1));
   // the scene box, from the root record's two child boxes: its largest coordinate magnitude (RenderArgs::reach_slack), and whether
-  // every axis of the quantised grid resolves the rounding of a primitive's own box planes (near_first_ok: coordinates below
-  // 128 extents, i.e. ulp(coordinate) below half a grid step -- the condition under which the outward-rounded quantised boxes
-  // cover what float rounding can do to a sphere's hit distance against its box)
+  // the grid of the quantised records resolves the scene's coordinates (grid_ok: on every axis they stay below 64 extents, i.e.
+  // ulp(coordinate) below a quarter of a grid step).  Only then do the outward-rounded quantised boxes cover what float rounding
+  // does to a primitive's own box planes and to a sphere's hit distance against them; a scene that fails
+  // the test -- one that sits far from the world origin compared with its size -- is walked over the exact records.
   sc->coord_max = 0.0f;
-  sc->near_first_ok = false;
+  sc->grid_ok = false;
   if (n > 1) {
     float rec[12];      // left x, y | left z, right x | right y, z  (min, max pairs)
     MIRT_HIP(hipMemcpy(rec, sc->nodes, sizeof(rec), hipMemcpyDeviceToHost));
     for (float v : rec) sc->coord_max = fmaxf(sc->coord_max, fabsf(v));
-    sc->near_first_ok = true;
+    sc->grid_ok = true;
     for (int k = 0; k < 3; ++k) {
       const float lo = fminf(rec[2 * k], rec[6 + 2 * k]), hi = fmaxf(rec[2 * k + 1], rec[6 + 2 * k + 1]);
-      if (!(fmaxf(fabsf(lo), fabsf(hi)) <= 128.0f * (hi - lo))) sc->near_first_ok = false;
+      if (!(fmaxf(fabsf(lo), fabsf(hi)) <= 64.0f * (hi - lo))) sc->grid_ok = false;
     }
   }
   // root: node 0, unless the whole scene is a single primitive

@@ -81,6 +81,10 @@ __global__ void __launch_bounds__(TRACE_BLOCK, MIRT_WAVES_PER_SIMD) trace_kernel
   constexpr int SPEC = SPECX;
   constexpr bool NOTRI = (SPEC & SPEC_NOTRI) != 0;
   constexpr bool WIDE = QN && !NOTRI;
+  // a finished shadow ray towards a point light that hit something, in a walk that is not the reference's own: the hit is vetted
+  // by the shade phase before batch_next reads "occluded" off it (hit_needs_literal_walk); no such lanes in a kernel without bulbs
+#define MIRT_HELD (QN && !(SPEC & SPEC_NOBULB) && h.reach_check && S.batch_pending && !S.trav && S.li >= h.num_suns && S.li < h.num_suns + h.num_bulbs && \
+                   S.refbest != REF_NONE)
   __shared__ __attribute__((aligned(16))) unsigned char lds_raw[STACK_LDS * TRACE_BLOCK * 4];     // traversal stacks: STACK_LDS x TRACE_BLOCK words
   // The random-number state (8 words per lane) is only touched in the shade phase: it lives here during traversal so
   // that it does not occupy registers across the hot loop (the kernel runs at the 128-VGPR edge of 4 waves per SIMD).
@@ -134,7 +138,9 @@ __global__ void __launch_bounds__(TRACE_BLOCK, MIRT_WAVES_PER_SIMD) trace_kernel
     // frame) has its ray walked again here, the reference's way, before the hit is shaded below -- while the sixteen parked words
     // of the lane are still in LDS: with them in registers the walk's own pushed spills into the whole shade phase (+1..3 %).
     // (the lanes vetted are exactly those the loop below lets advance() consume: none is looked at twice)
-    if (a.reach_check && !S.trav && S.g >= 0 && !(exhausted && S.batch_pending) && (!S.batch_pending || S.li >= a.num_suns + a.num_bulbs)) {
+    // (a batch lane: its reflection ray, or a shadow ray towards a point light -- one that hit something is left to this phase
+    // by the traversal loop's header, MIRT_HELD)
+    if (a.reach_check && !S.trav && S.g >= 0 && !(exhausted && S.batch_pending && !MIRT_HELD) && (!S.batch_pending || S.li >= a.num_suns)) {
       if (hit_needs_literal_walk<QN>(a, S)) walk_literally<COUNT, NOTRI>(a, S, cn, gid, gthreads);
     }
     {
@@ -146,7 +152,7 @@ __global__ void __launch_bounds__(TRACE_BLOCK, MIRT_WAVES_PER_SIMD) trace_kernel
       S.wD = mk3(__uint_as_float(p1.x), __uint_as_float(p1.y), __uint_as_float(p1.z)); S.Hior = __uint_as_float(p1.w);
     }
     // (once the frame's queue is empty the first ray of a new batch is started by the traversal loop's header instead)
-    while (!S.trav && S.g >= 0 && !(exhausted && S.batch_pending)) {
+    while (!S.trav && S.g >= 0 && !(exhausted && S.batch_pending && !MIRT_HELD)) {
       if (S.batch_pending) batch_next<COUNT, QN, RenderArgs, SPEC>(a, S, cn);
       else advance<COUNT, QN, SPEC>(a, S, cn, gid, gthreads);
     }
@@ -207,19 +213,21 @@ __global__ void __launch_bounds__(TRACE_BLOCK, MIRT_WAVES_PER_SIMD) trace_kernel
     const float tmin = 0.0001f;
     for (;;) {
       const unsigned long long tm = __ballot(S.trav);
-      const unsigned long long bm = __ballot(!S.trav && S.batch_pending);
+      // lanes whose batch ray finished and whose next one this header may start (not MIRT_HELD ones: the shade phase vets them)
+      const bool pend = !S.trav && S.batch_pending && !MIRT_HELD;
+      const unsigned long long bm = __ballot(pend);
       if (tm == 0 && bm == 0) break;
       // leave when enough lanes are waiting to shade (they cannot progress while the wave keeps traversing); a wave with
       // few live lanes (the drain at the end of the frame) does not wait for company: there the critical path is one
       // lane's bounce chain
       // lanes that wait: to shade, or (finished) for a new sample while the frame still has some
-      const int nwait = __popcll(__ballot(!S.trav && !S.batch_pending && (S.g >= 0 || !exhausted)));
+      const int nwait = __popcll(__ballot(!S.trav && !pend && (S.g >= 0 || !exhausted)));
       const int nlive = __popcll(__ballot(S.g >= 0));
       const bool drain = exhausted && nlive <= h.drain_lanes;
       if (nwait >= h.refill_k || (drain && nwait > 0)) break;
       // lanes whose batch ray finished move on to the next ray of their batch (cheap; done in groups)
       if (bm != 0 && (__popcll(bm) >= h.batch_k || tm == 0 || drain)) {
-        if (!S.trav && S.batch_pending) batch_next<COUNT, QN, HotArgs, SPEC>(h, S, cn);
+        if (pend) batch_next<COUNT, QN, HotArgs, SPEC>(h, S, cn);
       }
       // A wave executes the node path and the primitive path one after the other whenever its lanes are split between
       // them, and with ~45 live lanes nearly every iteration has a lane or two at a primitive.  So lanes that reach a
@@ -368,6 +376,7 @@ __global__ void __launch_bounds__(TRACE_BLOCK, MIRT_WAVES_PER_SIMD) trace_kernel
     }
   }
 }
+#undef MIRT_HELD
 
 // draw.cu:9-11
 MIRT_DEV unsigned char to_uchar_round(float f) { return (unsigned char)(fminf(fmaxf(f, 0.0f), 1.0f) * 255.0f + 0.5f); }
@@ -727,8 +736,10 @@ static int render_impl(MirtScene* sc, const MirtRenderParams* p, void* d_rgba8, 
   // 1.7 k primitives are 12 % faster on the exact records, the 2 M-primitive scene 25 % faster on the wide ones) or always (2).
   const bool notri = sc->Nt == 0;
   const bool qwant = opt.qnodes != 0 && opt.wavefront == 0;
-  const bool qn = notri ? (qwant && opt.traversal >= 1 && sc->root_ref_q != REF_NONE)
-                        : (qwant && opt.traversal == 1 && sc->root_ref_w != REF_NONE && (opt.qnodes >= 2 || sc->N >= 65536));
+  // (and only if the grid of the quantised records resolves the scene's coordinates: grid_ok, lbvh_build.hip -- a scene that
+  // sits hundreds of its own extents away from the world origin walks the exact records, in the reference's order)
+  const bool qn = sc->grid_ok && (notri ? (qwant && opt.traversal >= 1 && sc->root_ref_q != REF_NONE)
+                                        : (qwant && opt.traversal == 1 && sc->root_ref_w != REF_NONE && (opt.qnodes >= 2 || sc->N >= 65536)));
   // kernels specialised for what the scene does not have (SPEC_*, shade_common.h)
   const bool nobulb = opt.specialise != 0 && sc->d.num_bulbs == 0, nopend = opt.specialise != 0 && !need_pending;
   a.root_ref = qn ? (notri ? sc->root_ref_q : sc->root_ref_w) : sc->root_ref; a.num_spheres = sc->Ns; a.num_prims = sc->N;
@@ -738,9 +749,9 @@ static int render_impl(MirtScene* sc, const MirtRenderParams* p, void* d_rgba8, 
   // traversal = 1: near child first on the quantised records of a sphere-only scene, nowhere else.  Over the exact boxes the
   // reordered walk can cull a box over a sphere whose hit distance rounds below that box's entry distance (one ulp is enough; the
   // reference, in its order, gets there first): 13 of 4 000 far-camera fuzz scenes differed by a pixel or a ray.  The quantised
-  // boxes are rounded outwards by more than that rounding as long as the grid resolves it (near_first_ok) -- no differing byte
+  // boxes are rounded outwards by more than that rounding as long as the grid resolves it (grid_ok, a condition of qn) -- no differing byte
   // in 10 000 sphere scenes, 3 000 of them far-camera ones.  Everything else walks in the reference's order.
-  a.swap_mask = opt.traversal == 1 ? ((qn && notri && sc->near_first_ok) ? NODE_SWAP_PURE : 0u) : (opt.traversal == 2 ? NODE_SWAP_ANY : 0u);
+  a.swap_mask = opt.traversal == 1 ? ((qn && notri) ? NODE_SWAP_PURE : 0u) : (opt.traversal == 2 ? NODE_SWAP_ANY : 0u);
   a.skip_unlit = (opt.skip_unlit != 0 && sc->colors_finite && sc->d.num_suns + sc->d.num_bulbs <= 32) ? 1 : 0;
   a.shadow_anyhit = opt.shadow_anyhit != 0 ? 1 : 0;
   a.planes = sc->planes; a.num_planes = sc->d.num_planes;
@@ -858,8 +869,10 @@ static int render_impl(MirtScene* sc, const MirtRenderParams* p, void* d_rgba8, 
   h.nodes = a.nodes; h.root_ref = a.root_ref; h.swap_mask = a.swap_mask; h.qparams = a.qparams;
   h.planes = a.planes; h.num_planes = a.num_planes; h.suns = a.suns; h.num_suns = a.num_suns; h.bulbs = a.bulbs; h.num_bulbs = a.num_bulbs; h.shadow_anyhit = a.shadow_anyhit;
   h.stack_spill = a.stack_spill; h.lds_depth = a.lds_depth; h.refill_k = a.refill_k; h.batch_k = a.batch_k; h.drain_lanes = a.drain_lanes;
-  a.reach_check = ((qn || a.swap_mask != 0u) && sc->N > 1) ? 1 : 0;
+  // (the quantised walks; the exact records are walked in the reference's own order, or -- traversal = 2 -- in one that promises nothing)
+  a.reach_check = (qn && sc->N > 1) ? 1 : 0;
   a.reach_slack = 4.76837158203125e-07f * sc->coord_max;
+  h.reach_check = a.reach_check;
   h.leaf_k = opt.leaf_k > 0 ? opt.leaf_k : (qn ? 8 : 4);      // (exact records, redchair.txt: 4 is 1.3 % better than 8)
   h.reps = opt.reps > 0 ? opt.reps : ((qn && !notri) ? 5 : 4);      // (wide records: 5 is 1 % better on the 2 M-primitive scene, worse elsewhere)
   if (!wavefront && !cx.args_dev) MIRT_HIP(hipMalloc(&cx.args_dev, sizeof(RenderArgs) * MAX_SLAB_ARGS));

@@ -125,6 +125,7 @@ struct HotArgs {
   int lds_depth, refill_k, batch_k, drain_lanes;
   int reps;                       // traversal steps per pass through the loop header
   int leaf_k;                     // primitive tests are held back until this many lanes of the wave have one pending
+  int reach_check;                // RenderArgs::reach_check
 };
 
 struct ResolveArgs {
@@ -246,7 +247,7 @@ struct MirtScene {
   bool built = false;
   float build_ms = 0.0f;
   float coord_max = 0.0f;               // largest |coordinate| of the scene box (set by the build)
-  bool near_first_ok = false;           // the quantised grid is fine enough for near-child-first descent to be exact (set by the build)
+  bool grid_ok = false;                 // the grid of the quantised records resolves the scene's coordinates (set by the build): they may be walked
   // render workspaces: MIRT_MAX_FRAMES contexts so that several frames can be in flight on different streams (the next frame's blocks fill the
   // CUs the draining frame frees); a context is reused only after its previous frame has finished
   mirt::RenderCtx ctx[mirt::MIRT_MAX_FRAMES];

@@ -378,9 +378,11 @@ MIRT_DEV void set_ray(Lane& S, const RayS& r) { S.o = r.o; S.d = r.d; S.bounce =
 // per axis  T - t_enter >= ((r - |v|)(1 - 2.01u) - 2.1u(|c| + r + |o|)) / |d| - 2.01u T  for v = o + T d - c evaluated within
 // 3u(|o| + T + |c|), hence  r - |v| > 8u(|o| + |c| + r + T)  suffices, and |c| + r is at most the largest coordinate of the
 // scene box (`slack` = 2^-21 of it) -- says "provably reached" for all but a few hits per million; for the others the leaf
-// box test itself is evaluated.  Shadow rays need none of this: a ray to a sun is occluded iff any sphere is hit, in any order
-// (the reference culls by distance only once it has a hit); towards a point light the same holds unless an occluder's hit
-// distance and the light's agree to the ulp.
+// box test itself is evaluated.  A shadow ray to a sun needs none of this: it is occluded iff any sphere is hit, in any order
+// (the reference culls by distance only once it has a hit).  Towards a point light "occluded" means nearer than the light, and a
+// hit the reference never tests can be the one that is: from a point on an infinite plane 10^8 units away every sphere near the
+// light is within an ulp of the light's distance (the fuzzer again: seed 72, scene 2868).  Those rays are traced to their
+// nearest hit and vetted like the others (batch_next; the loop header leaves their results to the shade phase).
 // What stays an assumption is the mirror image: that no walk of the product CULLS a box over a sphere whose computed hit distance
 // lies below that box's entry distance and below the best distance of the moment, while the reference -- in its order -- gets
 // there first.  Over the quantised boxes that takes a disagreement of more than a grid step plus their 8-ulp margin; over the
@@ -401,7 +403,7 @@ MIRT_DEV bool hit_needs_literal_walk(const RenderArgs& a, const Lane& S)
   // (nothing to vet: no sphere hit, or the plane is nearer; the reference's own order over its own boxes; a ray that was already
   // walked again; a shading node without a reflection ray -- nothing was traced for it, advance_core's no_ray)
   if (S.refbest == REF_NONE || (S.refbest & REF_TRI) != 0u || !a.reach_check || (QN && S.qsx == 0u)) return false;
-  if ((S.plane_id >= 0 && !(S.tbest < S.tplane)) || (S.state == ST_BATCH && !S.has_reflect)) return false;
+  if ((S.plane_id >= 0 && !(S.tbest < S.tplane)) || (!S.batch_pending && S.state == ST_BATCH && !S.has_reflect)) return false;
   const float4 q = a.nodes[S.refbest & REF_OFFMASK];
   if (!hit_at_risk(q, S.o, S.d, S.tbest, a.reach_slack)) return false;
   float te, tx;
@@ -468,7 +470,9 @@ MIRT_DEV void batch_next(const Args& a, Lane& S, Counters& cn)
     S.limit = INFINITY;
     // shadow_anyhit = 0: the ray is traced to its nearest hit like any other, exactly as hitNearest does for diffuseLight
     // (draw.cu:347-352, 365-370); the occlusion test above reads the same boolean off the result either way
-    S.shadow = a.shadow_anyhit != 0;
+    // (towards a point light, in a walk that is not the reference's own, the ray is traced to its nearest hit all the same and
+    // that hit is vetted like any other -- hit_needs_literal_walk: "occluded" there means nearer than the light)
+    S.shadow = a.shadow_anyhit != 0 && (NOBULB || S.li < a.num_suns || !a.reach_check);
     S.bounce = 1;
     if (COUNT) cn.shadow_rays++;
     if (NOBULB || S.li < a.num_suns) {

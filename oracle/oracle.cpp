@@ -117,7 +117,7 @@ typedef struct {
  * the same order, which is all the argument under ORC_FLAG_QNODES needs.  Half as many dependent steps per ray.  Needs QNODES;
  * the descent order is the reference's at every node (no near-child-first, not even between sphere-only subtrees). */
 #define ORC_FLAG_WIDE          64u
-/* Any walk that is not the reference's own (another order, larger boxes) vets the sphere hit a nearest-hit query ends with
+/* A walk over the quantised boxes (ORC_FLAG_QNODES; the exact boxes are walked in the reference's order) vets the sphere hit a nearest-hit query ends with
  * before it is shaded (the product: hit_needs_literal_walk, shade_common.h): a sphere's hit distance can round to just below the
  * entry distance of its own leaf box -- a ray that touches the sphere where the sphere touches its box, from far away -- and
  * then the reference tests that sphere or not depending on what it found before, while another walk may end with it.  If the
@@ -928,16 +928,18 @@ static Obj check_plane(const Ctx& cx, const Ray& ray)
 }
 
 /* hitNearest, draw.cu:292-318 */
-static Obj hit_nearest(Ctx& cx, const Ray& ray, bool count_mat = true)
+/* vet: ORC_FLAG_REACH applies to this query (every query that is shaded; shadow queries towards point lights) */
+static Obj hit_nearest(Ctx& cx, const Ray& ray, bool count_mat = true, int vet = -1)
 {
+  if (vet < 0) vet = count_mat ? 1 : 0;
   if (ray.bounce == 0) return obj_none();
   cx.st.rays++;
   Obj b = traverse_any(cx, ray, INFINITY, false, -1.0f);
   Obj p = check_plane(cx, ray);
   const uint32_t N = (uint32_t)cx.sc->refs.size();
   /* ORC_FLAG_REACH: where the product reads the sphere's record to shade it, i.e. when the BVH hit is the nearer one */
-  if ((cx.flags & ORC_FLAG_REACH) && count_mat /* (not a shadow query) */ && b.isHit && b.kind == 1 && !b.literal && N > 1 &&
-      (!p.isHit || b.distance < p.distance) && (cx.flags & (ORC_FLAG_ORDERED | ORC_FLAG_ORDERED_ALL | ORC_FLAG_QNODES))) {
+  if ((cx.flags & ORC_FLAG_REACH) && vet && b.isHit && b.kind == 1 && !b.literal && N > 1 &&
+      (!p.isHit || b.distance < p.distance) && (cx.flags & ORC_FLAG_QNODES)) {
     const V3 inv = mk(1.0f / ray.dir.x, 1.0f / ray.dir.y, 1.0f / ray.dir.z);
     float te;
     const bool box_ok = hit_aabb_t(cx.sc->nodes[N - 1 + b.leaf], ray.eye, inv, 0.0001f, INFINITY, &te);
@@ -954,11 +956,15 @@ static Obj hit_nearest(Ctx& cx, const Ray& ray, bool count_mat = true)
 
 /* Shadow query = hitNearest on a bounce-1 ray followed by the caller's test (draw.cu:347-352, 365-370).
  * limit = +inf for suns (occluded iff anything is hit), |bulbDir| for bulbs (occluded iff distance < limit). */
-static bool occluded(Ctx& cx, const Ray& ray, float limit)
+static bool occluded(Ctx& cx, const Ray& ray, float limit, bool bulb = false)
 {
   cx.st.shadow_rays++;
-  if (!(cx.flags & ORC_FLAG_ANYHIT_SHADOW)) {
-    Obj h = hit_nearest(cx, ray, false);
+  /* ORC_FLAG_REACH, a walk that is not the reference's own, a point light: "occluded" means nearer than the light, and a hit the
+   * reference never tests can be the one that is (from far enough away every sphere near the light is within an ulp of the
+   * light's distance) -- the product traces these rays to their nearest hit and vets it like any other */
+  const bool vetted_bulb = bulb && (cx.flags & ORC_FLAG_REACH) && cx.sc->refs.size() > 1 && (cx.flags & ORC_FLAG_QNODES);
+  if (!(cx.flags & ORC_FLAG_ANYHIT_SHADOW) || vetted_bulb) {
+    Obj h = hit_nearest(cx, ray, false, vetted_bulb ? 1 : 0);
     return h.isHit && h.distance < limit;
   }
   /* early-exit form: same boolean, fewer node visits; the plane is asked first */
@@ -1019,7 +1025,7 @@ static C4 diffuse_light(Ctx& cx, const Obj& obj, Rng* rng)
     Ray sr = mkray(obj.i_point + obj.normal * 0.001f, bd, 1);
     const bool unlit = (cx.flags & ORC_FLAG_SKIP_UNLIT) && !(dot(normal, normalize(bd)) > 0.0f);
     if (unlit) { cx.st.rays++; cx.st.shadow_rays++; }
-    else if (occluded(cx, sr, length(bd))) continue;
+    else if (occluded(cx, sr, length(bd), true)) continue;
     float lambert = fmaxf(dot(normal, normalize(bd)), 0.0f);
     color = color + color_bulb(lambert, obj.mat.color, c3(sc.bulbs[i].color), length(bd), sc.d.expose);
   }

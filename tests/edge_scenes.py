@@ -144,7 +144,7 @@ def far_camera(n=400):
 def far_from_origin(n=300, offset=1000.0):
     """A unit-sized cluster of spheres 1 000 units from the world origin: ulp(coordinate) = 6e-5 is two steps of the quantised
     grid (2 / 65535), so the outward rounding of the quantised boxes no longer covers the rounding of a sphere's own box planes
-    -- the build clears `near_first_ok` and the quantised records are walked in the reference's order (lbvh_build.hip)."""
+    -- the build clears `grid_ok` and the scene is walked over the exact records, in the reference's order (lbvh_build.hip)."""
     rng = np.random.default_rng(12)
     out = [HEADER, "bounces 3\n", "eye %.1f 0.3 4\n" % offset, "forward 0 0 -1\n", "color 1 1 1\n", "sun 1 1 1\n", "sun -1 2 0.5\n",
            "color 0.6 0.6 0.6\n", "shininess 0.3\n", "plane 0 1 0 1\n", "shininess 0.5\n"]

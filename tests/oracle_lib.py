@@ -25,14 +25,14 @@ PRODUCT_FLAGS_SMALL_TRI = PRODUCT_ALWAYS                      # ... a smaller sc
 REFERENCE_WALK = 0      # {traversal: 0, shadow_anyhit: 0, skip_unlit: 0, qnodes: 0}: draw.cu:292-377 + bvh_traversal.cu:92-183 verbatim
 
 
-def product_flags(scene_has_triangles, traversal=1, wavefront=False, qnodes=1, shadow_anyhit=True, skip_unlit=True, nprims=0, near_first_ok=True):
+def product_flags(scene_has_triangles, traversal=1, wavefront=False, qnodes=1, shadow_anyhit=True, skip_unlit=True, nprims=0, grid_ok=True):
     """The oracle flags that mirror what libmirt does for an option set (for counters to compare with ==).  qnodes: the scene
-    option (0 never, 1 sphere-only scenes and scenes with triangles of 65536 primitives or more, 2 every scene).  traversal = 1
-    reorders only the walk over the quantised records of a sphere-only scene -- and only if the scene's grid resolves the rounding
-    of its coordinates (near_first_ok: OracleScene.near_first_ok()); everything else keeps the reference's order."""
-    quantised = bool(qnodes) and not wavefront and not scene_has_triangles and traversal >= 1
-    wide = bool(qnodes) and not wavefront and scene_has_triangles and traversal == 1 and (qnodes >= 2 or nprims >= 65536)
-    f = {0: 0, 1: FLAG_ORDERED if ((quantised and near_first_ok) or wide) else 0, 2: FLAG_ORDERED_ALL}[traversal]
+    option (0 never, 1 sphere-only scenes and scenes with triangles of 65536 primitives or more, 2 every scene) -- honoured only
+    if the grid of the quantised records resolves the scene's coordinates (grid_ok: OracleScene.grid_ok()).  traversal = 1
+    reorders only the walk over the quantised records of a sphere-only scene; everything else keeps the reference's order."""
+    quantised = grid_ok and bool(qnodes) and not wavefront and not scene_has_triangles and traversal >= 1
+    wide = grid_ok and bool(qnodes) and not wavefront and scene_has_triangles and traversal == 1 and (qnodes >= 2 or nprims >= 65536)
+    f = {0: 0, 1: FLAG_ORDERED if (quantised or wide) else 0, 2: FLAG_ORDERED_ALL}[traversal]
     if shadow_anyhit:
         f |= FLAG_ANYHIT_SHADOW
     if skip_unlit:
@@ -183,11 +183,11 @@ class OracleScene:
         lib().orc_get_refs(self.h, out.ctypes.data)
         return out
 
-    def near_first_ok(self):
-        """lbvh_build.hip: every axis of the scene box has its coordinates below 128 extents (float arithmetic as there)."""
+    def grid_ok(self):
+        """lbvh_build.hip: every axis of the scene box has its coordinates below 64 extents (float arithmetic as there)."""
         mn, mx = self.bounds()
         ext = (mx - mn).astype(np.float32)
-        return bool(np.all(np.maximum(np.abs(mn), np.abs(mx)) <= np.float32(128.0) * ext))
+        return bool(np.all(np.maximum(np.abs(mn), np.abs(mx)) <= np.float32(64.0) * ext))
 
     def bounds(self):
         mn = np.zeros(3, np.float32)

@@ -29,7 +29,7 @@ def run_case(text, w, h, spp, **options):
     raw.close()
     o = ol.OracleScene(pyscene.parse_lines(text.split("\n")), bounds_mode=0)
     ref = o.render(w, h, spp, flags=ol.product_flags(stl.num_triangles > 0, traversal=options.get("traversal", 1), qnodes=options.get("qnodes", 1),
-                                                      nprims=stl.num_prims, near_first_ok=o.near_first_ok()), nthreads=8)
+                                                      nprims=stl.num_prims, grid_ok=o.grid_ok()), nthreads=8)
     if tree is not None:
         on = o.nodes()
         for f in ("left", "right"):
@@ -79,17 +79,18 @@ def test_quantised_nodes_are_conservative_for_far_ray_origins():
     assert st_q["rays"] == st_l["rays"] == st_f["rays"] and st_f["internal_visits"] <= st_q["internal_visits"] < st_l["internal_visits"]
 
 
-def test_a_scene_far_from_the_origin_keeps_the_reference_order_on_the_quantised_records():
-    """edge_scenes.far_from_origin: coordinates 450 times the scene's extent -- the quantised grid is coarser than the rounding
-    of the primitives' own box planes, so near child first is not taken (near_first_ok, lbvh_build.hip): the quantised records in
-    the reference's order, counters equal to the oracle's mirror of exactly that, bytes and ray count of the exact records."""
+def test_a_scene_far_from_the_origin_is_walked_over_the_exact_records():
+    """edge_scenes.far_from_origin: coordinates 450 times the scene's extent -- the grid of the quantised records is coarser than
+    the rounding of the primitives' own box planes, so they are not used (grid_ok, lbvh_build.hip): the default options walk the
+    exact records in the reference's order -- counters equal to the oracle's mirror of exactly that (no QNODES, no ORDERED), and
+    to the counters of qnodes = 0."""
     text = edge_scenes.far_from_origin()
     o = ol.OracleScene(pyscene.parse_lines(text.split("\n")), bounds_mode=0)
-    assert not o.near_first_ok()
+    assert not o.grid_ok()
     o.close()
     st_q, img_q = run_case(text, 96, 72, 4)
     st_l, img_l = run_case(text, 96, 72, 4, qnodes=0)
-    assert np.array_equal(img_q, img_l) and st_q["rays"] == st_l["rays"] and st_q["internal_visits"] >= st_l["internal_visits"]
+    assert np.array_equal(img_q, img_l) and all(st_q[k] == st_l[k] for k in ("rays", "internal_visits", "sphere_tests"))
 
 
 @pytest.mark.parametrize("name", ["fisheye", "single_triangle", "glass_gi_dof"])

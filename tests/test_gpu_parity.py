@@ -384,6 +384,34 @@ def test_a_hit_the_reference_never_tests_sends_the_ray_over_its_literal_walk(qno
         assert ref["stats"]["qn_retraces"] == 1 and unvetted["stats"]["rays"] == plain["stats"]["rays"] + 1
 
 
+def test_a_shadow_ray_to_a_point_light_whose_occluder_the_reference_never_tests():
+    """tests/golden/far_plane_point_light.txt (tests/test_oracle_units.py has the story): shadow rays towards a point light are
+    traced to their nearest hit and vetted when the walk is over the quantised records -- every counter equals the oracle's
+    mirror (re-walks included), and the frame is the reference-walk mode's: bytes, float image, ray count."""
+    import pyscene
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "far_plane_point_light.txt")
+    stl = m.parseInput(path)
+    raw = m.initRawConfigFromStl(stl, 0)
+    m.build_lbvh_karas(raw)
+    osc = ol.OracleScene(pyscene.parse_lines(open(path).read().split("\n")), bounds_mode=0)
+    w, h, spp = 192, 108, 2
+    try:
+        a8, af = gpu_render(raw, w, h, spp, counters=True)
+        sa = raw.stats()
+        with options(raw, **REFERENCE_WALK):
+            b8, bf = gpu_render(raw, w, h, spp, counters=True)
+            sb = raw.stats()
+        ref = osc.render(w, h, spp, flags=ol.product_flags(False, grid_ok=osc.grid_ok()), nthreads=8)
+        plain = osc.render(w, h, spp, flags=0, nthreads=8)
+    finally:
+        raw.close()
+    assert ref["stats"]["qn_retraces"] > 0
+    for k in COUNTER_KEYS:
+        assert sa[k] == ref["stats"][k], (k, sa[k], ref["stats"][k])
+        assert sb[k] == plain["stats"][k], (k, sb[k], plain["stats"][k])
+    assert np.array_equal(a8, b8) and np.array_equal(af.view(np.uint32), bf.view(np.uint32)) and sa["rays"] == sb["rays"]
+
+
 @pytest.mark.parametrize("name", ["tenthousand", "spiral", "redchair", "tri"])
 def test_default_traversal_gives_the_bytes_of_the_reference_order(name, gpu_scenes):
     """The ordered traversal changes which nodes are visited, never the closest hit: the whole 1920x1080 x 16 spp frame
@@ -430,15 +458,17 @@ def test_random_sphere_scenes_default_mode_equals_reference_order(tmp_path):
     assert fuzz_modes.main(["--scenes", "60", "--seed", "11", "--out", str(tmp_path)]) == 0
 
 
-@pytest.mark.parametrize("extra", [[], ["--triangles", "1.0", "--qnodes", "2"]], ids=["spheres", "mixed-wide"])
+@pytest.mark.parametrize("extra", [["--far"], ["--far", "--triangles", "1.0", "--qnodes", "2"], ["--offset"], ["--offset", "--far", "--triangles", "0.3", "--qnodes", "2"]],
+                         ids=["far-spheres", "far-mixed-wide", "offset-spheres", "offset-far-mixed-wide"])
 def test_far_camera_scenes_default_mode_equals_the_reference_walk_mode(extra, tmp_path):
-    """The regime of tests/golden/far_camera_tie.txt at random (fuzz_modes.py --far: cameras 10^3 .. 10^5 scene sizes away, many
-    large overlapping spheres; the oracle counts five literal re-walks per scene there on average): 100 scenes per kind, the
+    """The regimes of tests/golden/far_camera_tie.txt and far_plane_point_light.txt at random (fuzz_modes.py --far: cameras
+    10^3 .. 10^5 scene sizes away, many large overlapping spheres -- the oracle counts five literal re-walks per scene there on
+    average; --offset: the whole scene 3 .. 3000 of its sizes away from the world origin): 100 scenes per kind, the
     default mode -- rendered twice, the second time in the measured hand-out order -- against the reference-walk mode
     (traversal 0, shadow_anyhit 0, skip_unlit 0, qnodes 0): bytes, float image and ray count."""
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
     import fuzz_modes
-    assert fuzz_modes.main(["--scenes", "100", "--seed", "71", "--far", "--reference-walk", "--out", str(tmp_path)] + extra) == 0
+    assert fuzz_modes.main(["--scenes", "100", "--seed", "71", "--reference-walk", "--out", str(tmp_path)] + extra) == 0
 
 
 def test_shipped_tree_mode_reproduces_the_survey_golden_image(gpu_scenes, oracle_scenes):

@@ -254,6 +254,28 @@ def test_a_hit_below_the_entry_distance_of_its_own_box_is_vetted():
             assert whole[0]["stats"][k] == m["stats"][k], k
 
 
+def test_a_shadow_ray_to_a_point_light_from_very_far_away_is_vetted():
+    """tests/golden/far_plane_point_light.txt (three spheres of tools/fuzz_modes.py --offset --far, seed 72, scene 2868), pixel
+    (144, 65) of a 192x108 frame at 2 spp: a panorama ray hits the infinite plane 1.2e8 units away; from there the point light
+    and the two large spheres around it are all 121 323 3xx units away, ulp(t) = 8.  "Occluded" means nearer than the light: the
+    reference's walk ends with one sphere at t = ...344 (not nearer), the walk over the quantised boxes with the other at
+    t = ...328 (nearer) -- a hit the reference never tests -- and the pixel turns black.  With ORC_FLAG_REACH such shadow
+    queries are traced to their nearest hit and vetted like every shaded hit: image and ray count of the plain restatement."""
+    import os
+    import pyscene
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "far_plane_point_light.txt")
+    o = ol.OracleScene(pyscene.parse_lines(open(path).read().split("\n")), bounds_mode=0)
+    assert o.grid_ok()
+    tile = (144, 65, 1, 1)
+    plain = o.render(192, 108, 2, tile=tile, flags=0)
+    unvetted = o.render(192, 108, 2, tile=tile, flags=ol.PRODUCT_FLAGS & ~ol.FLAG_REACH)
+    vetted = o.render(192, 108, 2, tile=tile, flags=ol.PRODUCT_FLAGS)
+    assert not np.array_equal(plain["f32"], unvetted["f32"]) and np.array_equal(plain["f32"].view(np.uint32), vetted["f32"].view(np.uint32))
+    assert vetted["stats"]["qn_retraces"] >= 1 and vetted["stats"]["rays"] == plain["stats"]["rays"]
+    whole_plain, whole = o.render(192, 108, 2, flags=0, nthreads=8), o.render(192, 108, 2, flags=ol.PRODUCT_FLAGS, nthreads=8)
+    assert np.array_equal(whole_plain["f32"].view(np.uint32), whole["f32"].view(np.uint32)) and whole_plain["stats"]["rays"] == whole["stats"]["rays"]
+
+
 def test_far_camera_scenes_vetted_walk_equals_the_plain_restatement():
     """The regime of the finding above, at random (tools/fuzz_scenes.py, far = True: cameras 10^3 .. 10^5 scene sizes away, many
     large overlapping spheres): the mirror of the product's default mode, vetting included, gives the float image and the ray

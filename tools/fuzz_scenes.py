@@ -2,10 +2,16 @@
 import numpy as np
 
 
-def scene_text(rng, tri_fraction=0.0, far=False):
+def scene_text(rng, tri_fraction=0.0, far=False, offset=False):
     """far: the regime of tests/golden/far_camera_tie.txt -- the camera 10^3 .. 10^5 scene sizes away (ulp(t) of the size of the
     spheres' features), many large overlapping spheres: sphere hits that round below the entry of their own boxes are common."""
     scale = 10.0 ** rng.uniform(-3, 6)
+    # offset: the whole scene (camera, primitives, point lights) moved away from the world origin by 3 .. 3000 scene sizes --
+    # coordinates whose ulp approaches the quantised grid's step (near_first_ok, lbvh_build.hip) and the spheres' features
+    off = np.zeros(3)
+    if offset:
+        v = rng.normal(size=3)
+        off = v / np.linalg.norm(v) * scale * 10.0 ** rng.uniform(0.5, 3.5)
     n = int(10 ** rng.uniform(0.3, 2.7 if far else 3.7))
     lines = ["png 64 64 fuzz.png", "bounces %d" % rng.integers(1, 8)]
     mode = rng.integers(0, 4)
@@ -19,7 +25,7 @@ def scene_text(rng, tri_fraction=0.0, far=False):
     eye = eye / np.linalg.norm(eye) * dist * scale
     if rng.random() < 0.3:              # axis-aligned view: exact zeros in ray directions
         eye = np.array([0.0, 0.0, dist * scale])
-    lines.append("eye %.9g %.9g %.9g" % tuple(eye))
+    lines.append("eye %.9g %.9g %.9g" % tuple(eye + off))
     fwd = -eye if np.linalg.norm(eye) > 0 else np.array([0.0, 0.0, -1.0])
     if where == 2:
         fwd = fwd * 30.0               # long lens
@@ -36,7 +42,7 @@ def scene_text(rng, tri_fraction=0.0, far=False):
         lines.append("sun %.4f %.4f %.4f" % tuple(rng.normal(size=3)))
     if general and rng.random() < 0.6:
         lines.append("color 1 0.9 0.8")
-        lines.append("bulb %.6g %.6g %.6g" % tuple(rng.normal(size=3) * 2 * scale))
+        lines.append("bulb %.9g %.9g %.9g" % tuple(rng.normal(size=3) * 2 * scale + off))
     if rng.random() < 0.7:
         lines.append("color 0.5 0.5 0.5")
         lines.append("plane 0 1 0 %.6g" % (1.5 * scale))
@@ -49,7 +55,7 @@ def scene_text(rng, tri_fraction=0.0, far=False):
             lines.append("roughness %.3f" % rng.choice([0.0, 0.05, 0.3]))
         if general and rng.random() < 0.05:
             lines.append("transparency %.2f" % rng.choice([0.0, 0.7]))
-        c = rng.normal(size=3) * scale
+        c = rng.normal(size=3) * scale + off
         r = scale * 10.0 ** rng.uniform(-2.5, 0.3)
         if rng.random() < (0.3 if far else 0.05):
             r = scale * 3.0             # a big sphere that contains many others
@@ -59,7 +65,7 @@ def scene_text(rng, tri_fraction=0.0, far=False):
         for _ in range(int(n * tri_fraction) + 1):
             if rng.random() < 0.3:
                 lines.append("color %.3f %.3f %.3f" % tuple(rng.uniform(0.1, 1.0, 3)))
-            c = rng.normal(size=3) * scale
+            c = rng.normal(size=3) * scale + off
             size = scale * 10.0 ** rng.uniform(-2.0, 0.0)
             for _k in range(3):
                 v = c + rng.normal(size=3) * size
