@@ -105,7 +105,11 @@ void mirt_scene_destroy(MirtScene* sc);
  *                         65536 primitives or more walk the wide records (the boxes of a node's four grandchildren per 64-byte
  *                         record, two levels per step, the reference's order: traversal 1 only; a triangle hit the reference's
  *                         walk may not reach sends its ray over the exact records again).  2: every scene.  0: never.  Same
- *                         pixels in every case; not with wavefront
+ *                         pixels in every case; not with wavefront; and only where the records' grid resolves the scene's
+ *                         coordinates (on every axis below 64 extents of the scene box: a scene that sits far from the world
+ *                         origin compared with its size walks the exact records).  Over the quantised records the sphere hit
+ *                         a nearest-hit walk ends with -- shadow rays to point lights included -- is checked against the
+ *                         reference's own box test, and a ray whose hit the reference may never test is walked again its way
  *     "shadow_anyhit"     0/1 (default 1): a shadow ray ends at its first occluder; 0: a nearest-hit query like every other ray,
  *                         as diffuseLight does (draw.cu:347-352, 365-370) -- same boolean, more node visits
  *     "skip_unlit"        0/1 (default 1): shadow rays towards lights the shading normal faces away from are not traced (their
