@@ -40,13 +40,15 @@ def main(argv=None):
     ap.add_argument("--qnodes", type=int, default=1, help="scene option qnodes of the first render (2: quantised records on every scene, i.e. the wide walk on the mixed ones)")
     ap.add_argument("--far", action="store_true", help="every camera 10^3 .. 10^5 scene sizes away, many large overlapping spheres (scene_text)")
     ap.add_argument("--offset", action="store_true", help="every scene moved 3 .. 3000 scene sizes away from the world origin (scene_text)")
+    ap.add_argument("--lights", action="store_true", help="every scene has a point light and an infinite plane (and the general kernels: glass / gi now and then)")
+    ap.add_argument("--dups", action="store_true", help="a third of the spheres are exact copies of earlier ones: ties in the hit distance everywhere")
     ap.add_argument("--reference-walk", action="store_true", help="compare with {traversal 0, shadow_anyhit 0, skip_unlit 0, qnodes 0}: the reference's walk ray for ray")
     args = ap.parse_args(argv)
     rng = np.random.default_rng(args.seed)
     bad = 0
     visits = [0, 0]
     for i in range(args.scenes):
-        text = scene_text(rng, args.triangles, args.far, args.offset)
+        text = scene_text(rng, args.triangles, args.far, args.offset, args.lights, args.dups)
         w, h, spp = 192, 108, int(rng.choice([0, 1, 2, 4]))
         stl = m.parseText(text)
         raw = m.initRawConfigFromStl(stl, 0)

@@ -2,7 +2,7 @@
 import numpy as np
 
 
-def scene_text(rng, tri_fraction=0.0, far=False, offset=False):
+def scene_text(rng, tri_fraction=0.0, far=False, offset=False, lights=False, dups=False):
     """far: the regime of tests/golden/far_camera_tie.txt -- the camera 10^3 .. 10^5 scene sizes away (ulp(t) of the size of the
     spheres' features), many large overlapping spheres: sphere hits that round below the entry of their own boxes are common."""
     scale = 10.0 ** rng.uniform(-3, 6)
@@ -34,18 +34,19 @@ def scene_text(rng, tri_fraction=0.0, far=False, offset=False):
     lines.append("forward %.9g %.9g %.9g" % tuple(fwd))
     if rng.random() < 0.3:
         lines.append("dof %.6g %.6g" % (dist * scale, 0.01 * scale))
-    general = rng.random() < 0.25
+    general = lights or rng.random() < 0.25      # (lights: every scene has a point light, an infinite plane, glass / gi now and then)
     if general and rng.random() < 0.5:
         lines.append("gi %d" % rng.integers(1, 3))
     for _ in range(rng.integers(1, 4)):
         lines.append("color %.3f %.3f %.3f" % tuple(rng.uniform(0.3, 1.2, 3)))
         lines.append("sun %.4f %.4f %.4f" % tuple(rng.normal(size=3)))
-    if general and rng.random() < 0.6:
+    if general and (lights or rng.random() < 0.6):
         lines.append("color 1 0.9 0.8")
         lines.append("bulb %.9g %.9g %.9g" % tuple(rng.normal(size=3) * 2 * scale + off))
-    if rng.random() < 0.7:
+    if lights or rng.random() < 0.7:
         lines.append("color 0.5 0.5 0.5")
         lines.append("plane 0 1 0 %.6g" % (1.5 * scale))
+    placed = []
     for _ in range(n):
         if rng.random() < 0.3:
             lines.append("color %.3f %.3f %.3f" % tuple(rng.uniform(0.1, 1.0, 3)))
@@ -59,6 +60,9 @@ def scene_text(rng, tri_fraction=0.0, far=False, offset=False):
         r = scale * 10.0 ** rng.uniform(-2.5, 0.3)
         if rng.random() < (0.3 if far else 0.05):
             r = scale * 3.0             # a big sphere that contains many others
+        if dups and placed and rng.random() < 0.3:      # an exact copy of an earlier sphere (another material): every hit a tie
+            c, r = placed[rng.integers(0, len(placed))]
+        placed.append((c, r))
         lines.append("sphere %.9g %.9g %.9g %.9g" % (c[0], c[1], c[2], r))
     if tri_fraction > 0:
         # triangles among the spheres: the tree then has subtrees that must keep the reference's order
