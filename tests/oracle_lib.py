@@ -10,14 +10,15 @@ ORACLE_SO = os.path.join(ORACLE_DIR, "_build", "liboracle.so")
 
 FLAG_ANYHIT_SHADOW = 1
 FLAG_NORMAL_ZYX = 2
-FLAG_ORDERED = 4        # near child first where both subtrees hold spheres only (the product's default traversal)
+FLAG_ORDERED = 4        # near child first where both subtrees hold spheres only (the product: over the quantised records of a sphere-only scene)
 FLAG_ORDERED_ALL = 8    # near child first everywhere
 FLAG_SKIP_UNLIT = 16    # shadow rays towards lights the shading normal faces away from are not traced (their term is 0)
-# what libmirt does: any-hit shadow rays and no shadow rays to unlit lights, always; ordered traversal
-# where pixels cannot change, by default -- the oracle mirrors each so that the visit counters can be compared with ==
+# what libmirt does: any-hit shadow rays and no shadow rays to unlit lights, always; near child first over
+# the quantised records of a sphere-only scene, the reference's order everywhere else; the hit a quantised walk ends with vetted
+# -- the oracle mirrors each so that the visit counters can be compared with ==
 FLAG_QNODES = 32        # quantised node records (single-kernel path, traversal >= 1; triangle hits outside their exact leaf box re-walk the exact boxes)
 FLAG_WIDE = 64          # wide walk over the quantised records: grandchildren tested per step, reference order (scenes with triangles)
-FLAG_REACH = 128        # the sphere hit a nearest-hit query ends with is vetted; a ray whose hit the reference may not reach is walked literally (single-kernel path)
+FLAG_REACH = 128        # over quantised boxes: the sphere hit a nearest-hit query ends with (shadow queries to point lights included) is vetted; a ray whose hit the reference may not reach is walked literally
 PRODUCT_ALWAYS = FLAG_ANYHIT_SHADOW | FLAG_SKIP_UNLIT | FLAG_REACH      # (the defaults of the scene options shadow_anyhit / skip_unlit; the single-kernel path)
 PRODUCT_FLAGS = PRODUCT_ALWAYS | FLAG_ORDERED | FLAG_QNODES   # default options, single-kernel path, a scene WITHOUT triangles
 PRODUCT_FLAGS_TRI = PRODUCT_FLAGS | FLAG_WIDE                 # ... a scene with triangles and 65536 primitives or more (or qnodes = 2)

@@ -7,7 +7,7 @@ def scene_text(rng, tri_fraction=0.0, far=False, offset=False, lights=False, dup
     spheres' features), many large overlapping spheres: sphere hits that round below the entry of their own boxes are common."""
     scale = 10.0 ** rng.uniform(-3, 6)
     # offset: the whole scene (camera, primitives, point lights) moved away from the world origin by 3 .. 3000 scene sizes --
-    # coordinates whose ulp approaches the quantised grid's step (near_first_ok, lbvh_build.hip) and the spheres' features
+    # coordinates whose ulp approaches the quantised grid's step (grid_ok, lbvh_build.hip) and the spheres' features
     off = np.zeros(3)
     if offset:
         v = rng.normal(size=3)
