@@ -117,13 +117,14 @@ typedef struct {
  * the same order, which is all the argument under ORC_FLAG_QNODES needs.  Half as many dependent steps per ray.  Needs QNODES;
  * the descent order is the reference's at every node (no near-child-first, not even between sphere-only subtrees). */
 #define ORC_FLAG_WIDE          64u
-/* A walk over the quantised boxes (ORC_FLAG_QNODES; the exact boxes are walked in the reference's order) vets the sphere hit a nearest-hit query ends with
- * before it is shaded (the product: hit_needs_literal_walk, shade_common.h): a sphere's hit distance can round to just below the
+/* A walk over the quantised boxes (ORC_FLAG_QNODES; the exact boxes are walked in the reference's order) vets the sphere hit a
+ * nearest-hit query ends with before it is shaded (the product: hit_needs_literal_walk, shade_common.h): a sphere's hit distance can round to just below the
  * entry distance of its own leaf box -- a ray that touches the sphere where the sphere touches its box, from far away -- and
  * then the reference tests that sphere or not depending on what it found before, while another walk may end with it.  If the
  * exact leaf box passes its order-independent clauses and is entered before the hit, the reference provably reaches the leaf
- * (the argument under ORC_FLAG_QNODES); otherwise the ray is walked again by traverse(), literally.  Shadow queries are not
- * vetted (the product's argument: occluded iff anything is hit, in any order).  Not set for the wavefront path. */
+ * (the argument under ORC_FLAG_QNODES); otherwise the ray is walked again by traverse(), literally.  Shadow queries to suns
+ * are not vetted (occluded iff anything is hit, in any order); those to point lights -- "occluded" = nearer than the light -- are
+ * traced to their nearest hit and vetted the same way (occluded()).  Not set for the wavefront path. */
 #define ORC_FLAG_REACH         128u
 #define ORC_FLAG_ORDERED       4u
 #define ORC_FLAG_ORDERED_ALL   8u   /* near child first at every node (triangle silhouettes may differ from the reference order) */
